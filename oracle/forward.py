@@ -1,0 +1,75 @@
+"""Oracle: the whole hot path -- DLA_PlanAWindow_l3new forward + heads + sigmoid + decode.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Restates
+  * DLA_PlanAWindow_l3new.imgpre2feats   sgtapose/lib/model/networks/dla.py:1505-1554
+  * BaseModelPlanA.forward (heads)       sgtapose/lib/model/networks/base_model.py:170-200
+  * SGTADetector.process                 sgtapose/lib/sgta_detector.py:881-927 (forward, sigmoid_, decode)
+"""
+import torch
+import torch.nn.functional as F
+
+from .dla34 import dla34_backbone, dla_up_forward, ida_up_forward
+from .temporal import topk_index, window_coords, window_gather, encoder_forward, substitute_tokens
+from .decode import dream_decode
+
+SCALE_LIST = (4, 2, 1, 1 / 2, 1 / 4, 1 / 8)       # dla.py:1493
+KS_DEFAULT = (12, 6, 3, 1, 1, 1)                  # opts_parallel.py:131-142 (ks1..ks6)
+HEADS = ("hm", "reg", "tracking")                  # 'wh' is skipped: base_model.py:114-115, :194-195
+
+
+def temporal_levels(x_pre, x_cur, pre_hm_cls, repro_hm_cls, sd, ks=KS_DEFAULT, use_pos=True,
+                    levels=range(6)):
+    """Levels 0-2: windowed cross-attention encoder then cat-MLP substitution; levels 3-5: the
+    previous frame's tokens go straight into the cat-MLP (dla.py:1513-1543).  K_i = 1 everywhere."""
+    pre_idx = topk_index(pre_hm_cls)
+    cur_idx = topk_index(repro_hm_cls)
+    out = list(x_cur)
+    fids = {}
+    for i in levels:
+        pre_f, cur_f = x_pre[i], x_cur[i]
+        H, W = cur_f.shape[2:]
+        pre_fid = window_coords(pre_idx, SCALE_LIST[i], ks[i], H, W)
+        cur_fid = window_coords(cur_idx, SCALE_LIST[i], ks[i], H, W)
+        key = window_gather(pre_f, pre_fid)
+        if i <= 2:
+            qry = window_gather(cur_f, cur_fid)
+            tok = encoder_forward(qry, key, key, sd, "transformer.%d" % i, use_pos=use_pos)
+        else:
+            tok = key
+        out[i] = substitute_tokens(tok, cur_f, cur_fid, sd, "cat_layer.%d" % i)
+        fids[i] = (pre_fid, cur_fid)
+    return out, fids
+
+
+def head_forward(feat, sd, name):
+    """conv3x3(64->256, bias) + ReLU + conv1x1(256->classes, bias)  (base_model.py:121-135)."""
+    h = F.relu(F.conv2d(feat, sd[name + ".0.weight"], sd[name + ".0.bias"], padding=1))
+    return F.conv2d(h, sd[name + ".2.weight"], sd[name + ".2.bias"])
+
+
+def plan_a_window_forward(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls,
+                          ks=KS_DEFAULT, use_pos=True, return_feats=False):
+    """Returns {'hm': logits [B,7,h,w], 'reg': [B,2,h,w], 'tracking': [B,2,h,w]} (what model(...)[-1] is)."""
+    with torch.no_grad():
+        x_pre = dla34_backbone(pre_img, pre_hm, sd)
+        x_cur = dla34_backbone(x, repro_hm, sd)
+        x_out, fids = temporal_levels(x_pre, x_cur, pre_hm_cls, repro_hm_cls, sd, ks, use_pos)
+        ups = dla_up_forward(x_out, sd)
+        y = [ups[0].clone(), ups[1].clone(), ups[2].clone()]
+        ida_up_forward(y, 0, 3, sd, "ida_up")
+        feat = y[-1]
+        out = {h: head_forward(feat, sd, h) for h in HEADS}
+        if return_feats:
+            out["_feat"] = feat
+            out["_x_out"] = x_out
+            out["_fids"] = fids
+        return out
+
+
+def process_reference(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, K=7, **kw):
+    """SGTADetector.process for phase PlanA_win: forward, in-place sigmoid on 'hm', decode.
+    Returns (output dict with post-sigmoid hm, dets dict of numpy arrays)."""
+    out = plan_a_window_forward(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, **kw)
+    out["hm"] = out["hm"].sigmoid_()
+    dets = dream_decode(out, K=K)
+    return out, {k: v.detach().cpu().numpy() for k, v in dets.items()}

@@ -1,0 +1,78 @@
+"""Seeded INPUTS of the per-operator golden cases (shared by make_golden.py and the tests, so the
+fixtures only need to store the reference's outputs).  Contains no reference code."""
+import numpy as np
+import torch
+
+LEVEL_SCALE = (4, 2, 1, 1 / 2, 1 / 4, 1 / 8)
+LEVEL_KS = (12, 6, 3, 1, 1, 1)
+
+
+def window_case():
+    """Prior maps on a 32x32 grid (sample 0: corners / borders / overlaps / a tie; sample 1: random,
+    one all-zero class) and random feature pyramids [2, 16*2^i, 128>>i, 128>>i]."""
+    g = torch.Generator().manual_seed(11)
+    h = 32
+    pre_cls = torch.zeros(2, 7, h, h)
+    cur_cls = torch.zeros(2, 7, h, h)
+    pts = [(0, 0), (31, 31), (0, 17), (30, 1), (15, 15), (16, 15), (5, 31)]
+    for k, (x, y) in enumerate(pts):
+        pre_cls[0, k, y, x] = 1.0
+        cur_cls[0, k, (y + 1) % h, x] = 0.7
+    cur_cls[0, 3, 4, 9] = 0.7                    # tie with the later blob -> lowest flat index wins
+    pre_cls[1] = torch.rand(7, h, h, generator=g)
+    cur_cls[1] = torch.rand(7, h, h, generator=g)
+    cur_cls[1, 6] = 0                            # all-zero map -> index 0
+    levels = []
+    for i in range(6):
+        C, H = 16 * 2 ** i, (4 * h) >> i
+        pre_f = torch.randn(2, C, H, H, generator=g)
+        cur_f = torch.randn(2, C, H, H, generator=g)
+        n = 7 * (1 + 2 * (LEVEL_KS[i] // 2)) ** 2
+        tok = torch.randn(2, n, C, generator=g)
+        levels.append((pre_f, cur_f, tok))
+    # non-square maps (reference needs python -O): 24x40 grid
+    pcn = torch.zeros(1, 7, 24, 40)
+    for k, (x, y) in enumerate([(39, 23), (0, 0), (25, 3), (38, 22), (13, 13), (23, 23), (30, 7)]):
+        pcn[0, k, y, x] = 1.0
+    fn = torch.randn(1, 8, 24, 40, generator=g)
+    fn2 = torch.randn(1, 8, 12, 20, generator=g)
+    return dict(pre_cls=pre_cls, cur_cls=cur_cls, levels=levels, ns_cls=pcn, ns_f=fn, ns_f2=fn2)
+
+
+def encoder_case():
+    g = torch.Generator().manual_seed(23)
+    out = []
+    for i, n in enumerate((1183, 343, 63)):
+        C = 16 * 2 ** i
+        B = 2 if i else 1
+        q = torch.randn(B, n, C, generator=g)
+        k = torch.randn(B, n, C, generator=g)
+        out.append((q, k))
+    return out
+
+
+def decode_case():
+    """Crafted post-sigmoid maps [2,7,40,48] + random reg / tracking heads."""
+    from sgtapose_amd.synthetic import peaked_heatmaps
+    H, W = 40, 48
+    hm, _ = peaked_heatmaps(2, H, W, seed=5)
+    m = hm.numpy().copy()
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+
+    def blob(cx, cy, a):
+        return a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / 8.0)
+
+    m[0, 1] = 0.002 + blob(10.3, 9.6, 0.8) + blob(35.2, 28.1, 0.7)    # two peaks, |gap| < 0.25 -> missing
+    m[0, 2] = 0.002 + blob(12.5, 30.2, 0.9) + blob(33.0, 8.0, 0.3)    # larger-y peak is the strong one -> kept
+    m[0, 3] = 0.002 + blob(12.5, 8.2, 0.9) + blob(33.0, 30.0, 0.3)    # larger-y peak is the weak one -> missing
+    m[0, 4] = 0.002                                                    # flat below threshold -> no peak
+    m[0, 5] = 0.002 + blob(0.2, 0.4, 0.9)                              # border peak
+    m[0, 6] = 0.002 + blob(46.8, 38.9, 0.9)                            # far-corner peak
+    m[1, 0] = 0.0105                                                   # flat above threshold: every pixel a peak
+    m[1, 1] = 0.0
+    m[1, 1, 20, 20] = 0.05                                             # lone spike: filtered max < threshold
+    hm = torch.from_numpy(m.astype(np.float32))
+    g = torch.Generator().manual_seed(7)
+    reg = torch.rand(2, 2, H, W, generator=g)
+    trk = torch.randn(2, 2, H, W, generator=g)
+    return hm, reg, trk

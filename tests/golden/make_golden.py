@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own Python files.
+
+Run in the build container only (needs /root/reference):
+
+    python -O tests/golden/make_golden.py
+
+``-O`` disables the reference's ``assert H == W`` (dla.py:931) so the non-square (480x640) vectors
+can be produced; nothing else depends on asserts.  torch runs with ONE thread: torch's CPU
+``index_put_`` is only deterministic for duplicate indices when serial (last write wins), and the
+reference's scatter-back (dla.py:1012-1014) hits duplicates on every frame (overlapping / clamped
+windows).  That serial behaviour is the canonical semantics of this build.
+
+Fixtures are DATA ONLY: seeds + the reference's outputs (inputs and weights are regenerated from the
+seeds by sgtapose_amd/synthetic.py on whatever machine runs the tests).  The un-vendored DCNv2
+extension is replaced by oracle/dcnv2.py (parity unpinned for that operator, see oracle/__init__.py).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+from ref_import import build_reference_model, load_reference  # noqa: E402
+from sgtapose_amd.synthetic import fill_state_dict_, make_inputs  # noqa: E402
+import cases  # noqa: E402
+
+torch.set_num_threads(1)
+ARGS = ("x", "pre_img", "pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def fullnet(model, tag, B, H, W, seed, first_frame=False, extra=False):
+    ref = load_reference()
+    inp = make_inputs(B, H, W, seed=seed, first_frame=first_frame)
+    opt = type("O", (), {"zero_tracking": False})()
+    with torch.no_grad():
+        out = model(*[inp[k] for k in ARGS])[-1]
+        hm_logits = out["hm"].clone()
+        out["hm"] = out["hm"].sigmoid_()
+        dets = []
+        for b in range(B):                       # the reference decodes batch element 0 only
+            ob = {k: v[b:b + 1].clone() for k, v in out.items()}
+            ob["pre_inds"] = None
+            dets.append(ref.decode.dream_generic_decode(ob, K=7, opt=opt))
+    arrs = dict(meta=np.array([B, H, W, seed, int(first_frame)]), hm_logits=hm_logits,
+                reg=out["reg"], tracking=out["tracking"])
+    for k in dets[0]:
+        arrs["det_" + k] = torch.cat([d[k] for d in dets], 0)
+    if extra:
+        # intermediate maps for kernel-level debugging (small resolutions only)
+        with torch.no_grad():
+            xp = model.base(pre_img=inp["pre_img"], pre_hm=inp["pre_hm"])
+            xc = model.base(pre_img=inp["x"], pre_hm=inp["repro_hm"])
+            feats, pf, cf = model.imgpre2feats(*[inp[k] for k in ARGS])
+        for i in (2, 3, 4, 5):
+            arrs["pre_l%d" % i] = xp[i]
+            arrs["cur_l%d" % i] = xc[i]
+        arrs["feat"] = feats[0]
+        arrs["pre_fid0"] = pf
+        arrs["cur_fid0"] = cf
+    save("fullnet_%s.npz" % tag, **arrs)
+
+
+def window_ops(model):
+    """get_topk_index / get_topk_features_scale / substitute_topk_features_scale (dla.py:898-1018).
+    Inputs come from cases.window_case(); only the reference's outputs are stored."""
+    dla = load_reference().dla
+    case = cases.window_case()
+    pi, ci = dla.get_topk_index(case["pre_cls"], case["cur_cls"], 1)
+    arrs = dict(pre_idx=pi, cur_idx=ci)
+    for i, (pre_f, cur_f, tok) in enumerate(case["levels"]):
+        sc, ks = model.scale_list[i], model.kernel_list[i]
+        pk, _, pf = dla.get_topk_features_scale(pre_f, pi, scale_num=sc, kernel=ks)
+        cq, cb, cf = dla.get_topk_features_scale(cur_f, ci, scale_num=sc, kernel=ks)
+        with torch.no_grad():
+            sub = dla.substitute_topk_features_scale(tok, cur_f, cb, cf, model.cat_layer[i])
+        B, C, H, W = cur_f.shape
+        touched = torch.zeros(B, H * W, dtype=torch.bool)
+        touched.scatter_(1, cf, True)
+        same = (sub == cur_f).reshape(B, C, -1).all(1)
+        assert bool((same | touched).all()), "substitute changed an untouched pixel"
+        sub_tok = torch.gather(sub.reshape(B, C, -1), 2, cf.view(B, 1, -1).expand(B, C, -1)).permute(0, 2, 1)
+        arrs.update({"pre_fid%d" % i: pf, "cur_fid%d" % i: cf, "key%d" % i: pk, "sub_tok%d" % i: sub_tok})
+    pin, _ = dla.get_topk_index(case["ns_cls"], case["ns_cls"], 1)
+    k1, _, f1 = dla.get_topk_features_scale(case["ns_f"], pin, scale_num=1, kernel=3)
+    k2, _, f2 = dla.get_topk_features_scale(case["ns_f2"], pin, scale_num=0.5, kernel=1)
+    arrs.update(ns_idx=pin, ns_fid=f1, ns_key=k1, ns_fid2=f2, ns_key2=k2)
+    save("window_ops.npz", **arrs)
+
+
+def encoder_ops(model):
+    """TransformerEncoder (3 x one shared layer) incl. MHCA_ein with non-zero pos_embed."""
+    arrs = {}
+    for i, (q, k) in enumerate(cases.encoder_case()):
+        with torch.no_grad():
+            lay = model.transformer[i].layers[0]
+            arrs["mhca%d" % i] = lay.cross_attn(q, k, k)
+            arrs["layer%d" % i] = lay(q, k, k)
+            arrs["enc%d" % i] = model.transformer[i](q, k, k)
+    save("encoder_ops.npz", **arrs)
+
+
+def decode_ops():
+    ref = load_reference()
+    hm, reg, trk = cases.decode_case()
+    arrs = {}
+    opt = type("O", (), {"zero_tracking": False})()
+    for b in range(2):
+        peaks = ref.image_proc.peaks_from_belief_maps(hm[b], offset_due_to_upsampling=0.4395)
+        arrs["peaks_count_%d" % b] = np.array([len(p) for p in peaks])
+        arrs["peaks_flat_%d" % b] = np.array([[p[0], p[1], p[2]] for pl in peaks for p in pl],
+                                             dtype=np.float64).reshape(-1, 3)
+        out = {"hm": hm[b:b + 1].clone(), "reg": reg[b:b + 1], "tracking": trk[b:b + 1], "pre_inds": None}
+        dets = ref.decode.dream_generic_decode(out, K=7, opt=opt)
+        for k, v in dets.items():
+            arrs["det%d_%s" % (b, k)] = v
+    sa = ref.spatial_softmax.SoftArgmaxPavlo.__new__(ref.spatial_softmax.SoftArgmaxPavlo)
+    torch.nn.Module.__init__(sa)                 # its __init__ hard-codes .cuda(); set fields by hand
+    sa.avgpool = torch.nn.AvgPool2d(7, stride=1, padding=3)
+    sa.beta = torch.ones(7) * 25.0
+    arrs["softargmax"] = sa(hm)
+    save("decode_ops.npz", **arrs)
+
+
+def main():
+    model, opt = build_reference_model()
+    sd = model.state_dict()
+    keys = [[k, list(v.shape)] for k, v in sd.items()]
+    with open(os.path.join(HERE, "model_keys.json"), "w") as f:
+        json.dump({"arch": "dlapawdl3new_34", "n_keys": len(keys), "keys": keys}, f)
+    print("wrote model_keys.json (%d keys)" % len(keys))
+    fill_state_dict_(sd, seed=0)
+    window_ops(model)
+    encoder_ops(model)
+    decode_ops()
+    fullnet(model, "128", 2, 128, 128, 317, extra=True)
+    fullnet(model, "128_first", 1, 128, 128, 318, first_frame=True)
+    fullnet(model, "96x160", 1, 96, 160, 319)
+    fullnet(model, "480", 1, 480, 480, 320)
+    fullnet(model, "480x640", 1, 480, 640, 321)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,115 @@
+"""CPU: the oracle (our restatement) against golden vectors produced by the reference's own files
+(tests/golden/make_golden.py).  Bit-exact where the oracle issues the same torch ops."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+from oracle import temporal as T
+from sgtapose_amd.synthetic import make_inputs
+from util import ARGS, golden, golden_state_dict
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_window_indices_and_gather_match_reference():
+    g = golden("window_ops.npz")
+    case = cases.window_case()
+    pi, ci = T.topk_index(case["pre_cls"]), T.topk_index(case["cur_cls"])
+    assert torch.equal(pi, t(g["pre_idx"])) and torch.equal(ci, t(g["cur_idx"]))
+    sd = golden_state_dict()
+    for i, (pre_f, cur_f, tok) in enumerate(case["levels"]):
+        H, W = cur_f.shape[2:]
+        pf = T.window_coords(pi, cases.LEVEL_SCALE[i], cases.LEVEL_KS[i], H, W)
+        cf = T.window_coords(ci, cases.LEVEL_SCALE[i], cases.LEVEL_KS[i], H, W)
+        assert torch.equal(pf, t(g["pre_fid%d" % i])), "pre fid level %d" % i
+        assert torch.equal(cf, t(g["cur_fid%d" % i])), "cur fid level %d" % i
+        assert torch.equal(T.window_gather(pre_f, pf), t(g["key%d" % i]))
+        sub = T.substitute_tokens(tok, cur_f, cf, sd, "cat_layer.%d" % i)
+        got = T.window_gather(sub, cf)
+        assert torch.allclose(got, t(g["sub_tok%d" % i]), atol=1e-5, rtol=1e-5), "substitute level %d" % i
+        untouched = torch.ones(cur_f.shape[0], H * W, dtype=torch.bool).scatter_(1, cf, False)
+        same = (sub == cur_f).reshape(cur_f.shape[0], cur_f.shape[1], -1).all(1)
+        assert bool(same[untouched].all())
+
+
+def test_window_nonsquare_clamps_both_axes_to_height():
+    g = golden("window_ops.npz")
+    case = cases.window_case()
+    idx = T.topk_index(case["ns_cls"])
+    assert torch.equal(idx, t(g["ns_idx"]))
+    f1 = T.window_coords(idx, 1, 3, 24, 40)
+    f2 = T.window_coords(idx, 0.5, 1, 12, 20)
+    assert torch.equal(f1, t(g["ns_fid"])) and torch.equal(f2, t(g["ns_fid2"]))
+    assert torch.equal(T.window_gather(case["ns_f"], f1), t(g["ns_key"]))
+    assert torch.equal(T.window_gather(case["ns_f2"], f2), t(g["ns_key2"]))
+
+
+def test_fractional_scale_index_quirk():
+    # kp (x=21,y=57) -> level 3 (28,40), level 4 (14,12), level 5 (7,4) as (y,x)
+    idx = torch.tensor([[[21.0, 57.0]]])
+    for scale, H, want in ((0.5, 60, (28, 40)), (0.25, 30, (14, 12)), (0.125, 15, (7, 4))):
+        fid = int(T.window_coords(idx, scale, 1, H, H)[0, 0])
+        assert (fid // H, fid % H) == want
+
+
+@pytest.mark.parametrize("i", [2, 1, 0])
+def test_encoder_matches_reference(i):
+    g = golden("encoder_ops.npz")
+    q, k = cases.encoder_case()[i]
+    sd = golden_state_dict()
+    p = "transformer.%d" % i
+    a = T.mhca_forward(q, k, k, sd, p + ".layers.0.cross_attn")
+    assert torch.allclose(a, t(g["mhca%d" % i]), atol=2e-5, rtol=1e-5)
+    one = T.encoder_layer_forward(q, k, k, sd, p + ".layers.0")
+    assert torch.allclose(one, t(g["layer%d" % i]), atol=2e-5, rtol=1e-5)
+    enc = T.encoder_forward(q, k, k, sd, p)
+    assert torch.allclose(enc, t(g["enc%d" % i]), atol=5e-5, rtol=1e-5)
+
+
+def test_gaussian_filter_restatement_is_scipy_bit_exact():
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.RandomState(0)
+    for shape in ((120, 160), (40, 48), (15, 9), (30, 7)):
+        m = rng.rand(*shape).astype(np.float32)
+        assert np.array_equal(oracle.gaussian_filter_f32(m), gaussian_filter(m, sigma=3))
+
+
+def test_decode_matches_reference():
+    g = golden("decode_ops.npz")
+    hm, reg, trk = cases.decode_case()
+    for b in range(2):
+        peaks = oracle.peaks_from_maps(hm[b].numpy())
+        assert [len(p) for p in peaks] == list(g["peaks_count_%d" % b])
+        flat = np.array([[p[0], p[1], p[2]] for pl in peaks for p in pl], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(flat, g["peaks_flat_%d" % b])
+        dets = oracle.dream_decode({"hm": hm[b:b + 1], "reg": reg[b:b + 1], "tracking": trk[b:b + 1]})
+        for k, v in dets.items():
+            ref = g["det%d_%s" % (b, k)]
+            assert tuple(v.shape) == ref.shape, k
+            assert np.array_equal(v.numpy(), ref), k
+    # whole batch at once == per-sample
+    dets = oracle.dream_decode({"hm": hm, "reg": reg, "tracking": trk})
+    assert np.array_equal(dets["cts_wreg"][1:].numpy(), g["det1_cts_wreg"])
+    sa = oracle.soft_argmax_pavlo(hm)
+    assert torch.allclose(sa, t(g["softargmax"]), atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["128", "128_first", "96x160", "480", "480x640"])
+def test_fullnet_matches_reference(tag):
+    g = golden("fullnet_%s.npz" % tag)
+    B, H, W, seed, first = [int(v) for v in g["meta"]]
+    inp = make_inputs(B, H, W, seed=seed, first_frame=bool(first))
+    sd = golden_state_dict()
+    out, dets = oracle.process_reference(sd, *[inp[k] for k in ARGS])
+    assert torch.allclose(torch.logit(out["hm"]), t(g["hm_logits"]), atol=1e-3)
+    assert torch.allclose(out["hm"], torch.sigmoid(t(g["hm_logits"])), atol=1e-6)
+    assert torch.allclose(out["reg"], t(g["reg"]), atol=1e-5)
+    assert torch.allclose(out["tracking"], t(g["tracking"]), atol=1e-5)
+    for k, v in dets.items():
+        ref = g["det_" + k]
+        assert v.shape == ref.shape, k
+        assert np.allclose(v, ref, atol=1e-5), k
