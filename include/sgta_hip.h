@@ -1,0 +1,126 @@
+/* libsgta_hip.so -- C ABI of the MI355X (gfx950) SGTAPose inference hot path.
+ *
+ * Drop-in boundary.  The reference's only FFI precedent is
+ * ``ctypes.cdll.LoadLibrary`` + ``extern "C" LM(double*, ..., int)`` (sgtapose/rf_tools/LM.py:10,
+ * :256-266); this library follows it: plain C functions, raw device pointers owned by the caller
+ * (inputs, outputs AND workspaces are allocated by the caller, e.g. torch), explicit sizes, the HIP
+ * stream as the last argument.  No global state, no allocation, no synchronisation inside: every
+ * entry point only enqueues kernels on ``stream`` and is safe to capture in a hipGraph and to call
+ * from several host threads on distinct streams.
+ *
+ * Return value: 0 = ok, < 0 = bad argument (SGTA_EBADARG = -1), > 0 = hipError_t of the launch.
+ * All tensors are contiguous float32 NCHW unless a batch stride ``*_bs`` (in ELEMENTS) is given,
+ * which lets a tensor be a channel slice of a larger (concatenation) buffer.
+ * ``pos`` / ``tok`` matrices are row-major [rows, ld].
+ *
+ * Each entry point names the reference code it replaces (paths relative to the reference repo).
+ */
+#ifndef SGTA_HIP_H
+#define SGTA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* sgta_stream_t; /* == hipStream_t */
+
+#define SGTA_OK 0
+#define SGTA_EBADARG (-1)
+#define SGTA_ACT_NONE 0
+#define SGTA_ACT_RELU 1
+#define SGTA_ACT_SIGMOID 2
+
+/* library version (major*1000 + minor*100 + patch) and device check (0 iff current device is gfx950) */
+int sgta_version(void);
+int sgta_check_device(void);
+
+/* conv2d (+ folded BatchNorm bias) (+ residual) (+ activation), implicit GEMM on f32 MFMA.
+ * Replaces torch Conv2d + BatchNorm2d(eval) + ReLU of the DLA-34 backbone, stems, Root/Tree/BasicBlock,
+ * the DCN offset/mask conv and the heads:
+ *   sgtapose/lib/model/networks/dla.py:41-69, :157-175, :178-231, :259-270, :302-312;
+ *   sgtapose/lib/model/networks/base_model.py:121-135.
+ * wt   : packed weights [Kpad][Cout_pad], Kpad = roundup(Cin*ks*ks, 16), Cout_pad = roundup(Cout, 32),
+ *        wt[(c*ks*ks + ky*ks + kx) * Cout_pad + co] = W[co][c][ky][kx] * bn_scale[co], zero padded
+ * bias : [Cout_pad] (BatchNorm shift / conv bias) or NULL
+ * res  : tensor with y's geometry added before (res_mode 1) or after (res_mode 2) the activation
+ * ks in {1,3,7}; tile 0 = auto (1: 32x256, 2: 64x256, 3: 128x128 couts x pixels per work-group). */
+int sgta_conv2d_f32(const float* x, long x_bs, const float* wt, const float* bias, const float* res,
+                    long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
+                    int Cout_pad, int Kpad, int ks, int stride, int pad, int act, int res_mode,
+                    int tile, sgta_stream_t stream);
+
+/* Modulated deformable 3x3 conv v2 (stride 1, pad 1, dil 1, 1 deformable group) + folded BN + act,
+ * gather fused into the GEMM (no column buffer).  Replaces the external lbin/DCNv2 ``dcn_v2_conv``
+ * (import dla.py:21-25, constructed dla.py:545, called dla.py:548) and DeformConv's BN+ReLU
+ * (dla.py:541-550).  ``om`` is the RAW 27-channel output of conv_offset_mask (channels 2k / 2k+1 =
+ * dy / dx of tap k, 18+k = mask logit; the sigmoid is applied here).
+ * wt : packed [9*Cin][Cout_pad] with k = tap*Cin + c (tap-major), Cin % 16 == 0. */
+int sgta_dcnv2_fwd_f32(const float* x, long x_bs, const float* om, long om_bs, const float* wt,
+                       const float* bias, float* y, long y_bs, int B, int Cin, int H, int W,
+                       int Cout, int Cout_pad, int act, int tile, sgta_stream_t stream);
+
+/* MaxPool2d(2,2)  (Tree.downsample, dla.py:209-210, :220). */
+int sgta_maxpool2_f32(const float* x, long x_bs, float* y, long y_bs, int B, int C, int H, int W,
+                      sgta_stream_t stream);
+
+/* y = ConvTranspose2d(C,C,2f,stride f,pad f/2,groups=C,bias=False)(x) + skip  (IDAUp, dla.py:561-577);
+ * w [C,1,2f,2f]; skip may be NULL; f in {2,4}. */
+int sgta_upsample_add_f32(const float* x, long x_bs, const float* w, const float* skip, long s_bs,
+                          float* y, long y_bs, int B, int C, int H, int W, int f, sgta_stream_t stream);
+
+/* element-wise sigmoid (SGTADetector._sigmoid_output, sgtapose/lib/sgta_detector.py:854-862). */
+int sgta_sigmoid_f32(const float* x, float* y, long n, sgta_stream_t stream);
+
+/* get_topk_index with K=1 (dla.py:898-913): idx_xy float32 [2][B][K][2] = (x, y) of the arg-max of
+ * pre_cls / cur_cls [B,K,h,w]; ties and all-zero maps -> lowest flat index. */
+int sgta_prior_argmax(const float* pre_cls, const float* cur_cls, float* idx_xy, int B, int K, int h,
+                      int w, sgta_stream_t stream);
+
+/* Window pixel ids of get_topk_features_scale (dla.py:915-968) for both frames of one pyramid level:
+ * fid int64 [2][B][n], n = K*(1+2*(ks/2))^2, x-major token order, fp32 coordinate math + truncation,
+ * both axes clamped to H-1.  win uint8 [B][n]: 1 iff no later token of the CURRENT frame targets the
+ * same pixel (ordered scatter of substitute_topk_features_scale, dla.py:1012-1014). */
+int sgta_window_index(const float* idx_xy, long long* fid, unsigned char* win, int B, int K,
+                      float scale, int ks, int H, int W, sgta_stream_t stream);
+
+/* tok[b*n + t][col0 + c] = feats[b][c][fid[b][t]]   (gather half of dla.py:961-966, :1012). */
+int sgta_window_gather(const float* feats, long f_bs, const long long* fid, float* tok, int B, int C,
+                       int H, int W, int n, int ld, int col0, sgta_stream_t stream);
+
+/* feats[b][c][fid[b][t]] = tok[b*n + t][c] for tokens with win == 1  (dla.py:1014). */
+int sgta_window_scatter(const float* tok, const long long* fid, const unsigned char* win, float* feats,
+                        long f_bs, int B, int C, int H, int W, int n, sgta_stream_t stream);
+
+/* y[M,N] = LN?( relu?(x[M,K] . w[N,K]^T + bias) + res ): nn.Linear of MHCA_ein (dla.py:860-864),
+ * the FFN (dla.py:721-732) and cat_layer (dla.py:1499-1502); LayerNorm (eps 1e-5) fused when
+ * ln_gamma != NULL (requires N <= 64).  K % 16 == 0. */
+int sgta_linear_f32(const float* x, int ldx, const float* w, const float* bias, const float* res,
+                    int ldr, const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M,
+                    int N, int K, int relu, sgta_stream_t stream);
+
+/* out[b,i,h*d:(h+1)*d] = softmax_j(q_i.k_j/sqrt(d) + pos_embed[h,i,j]) . v_j  per head
+ * (MHCA_ein.forward, dla.py:874-885); q/k/v/out row-major [B*n, ld*]; pos_embed [n_heads,n,n] or NULL;
+ * head_dim in {4,8,16}. */
+int sgta_mhca_fwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                      const float* pos_embed, float* out, int ldo, int B, int n, int n_heads,
+                      int head_dim, sgta_stream_t stream);
+
+/* peaks_from_belief_maps + _peaks_info + the gathers of dream_generic_decode
+ * (sgtapose/image_proc.py:1032-1143; sgtapose/lib/model/utils.py:207-284; sgtapose/lib/model/decode.py:184-313)
+ * for EVERY sample of the batch.  hm [B,K,H,W] post-sigmoid; reg / tracking [B,2,H,W] or NULL;
+ * gauss_w13: the 13 float64 taps w[0]=far .. w[12]=centre of scipy's sigma-3 kernel;
+ * ws_tmp / ws_filt: float32 workspaces of hm's size.  Outputs: scores f32 [B,K] (-1 = missing),
+ * xs / ys int64 [B,K], regs / trks f32 [B,K,2], npeaks int32 [B,K] (may be NULL). */
+int sgta_peaks_decode(const float* hm, const float* reg, const float* tracking, const double* gauss_w13,
+                      float* ws_tmp, float* ws_filt, float* scores, long long* xs, long long* ys,
+                      float* regs, float* trks, int* npeaks, int B, int K, int H, int W,
+                      sgta_stream_t stream);
+
+/* SoftArgmaxPavlo.forward (sgtapose/spatial_softmax.py:24-95): out_xy f32 [B,K,2] = (E[col], E[row]). */
+int sgta_softargmax(const float* hm, float* out_xy, int B, int K, int H, int W, float beta,
+                    float size_mult, sgta_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGTA_HIP_H */

@@ -1,0 +1,65 @@
+"""ctypes binding of libsgta_hip.so (the C ABI declared in include/sgta_hip.h).
+
+The library is the product: there is NO fallback.  If it is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsgta_hip.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_long
+_f = ctypes.c_float
+
+# name -> argtypes (return type is always int); must mirror include/sgta_hip.h
+SIGNATURES = {
+    "sgta_version": [],
+    "sgta_check_device": [],
+    "sgta_conv2d_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_dcnv2_fwd_f32": [_p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_maxpool2_f32": [_p, _l, _p, _l, _i, _i, _i, _i, _p],
+    "sgta_upsample_add_f32": [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "sgta_sigmoid_f32": [_p, _p, _l, _p],
+    "sgta_prior_argmax": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "sgta_window_index": [_p, _p, _p, _i, _i, _f, _i, _i, _i, _p],
+    "sgta_window_gather": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_window_scatter": [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
+    "sgta_linear_f32": [_p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_mhca_fwd_f32": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_peaks_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "sgta_softargmax": [_p, _p, _i, _i, _i, _i, _f, _f, _p],
+}
+
+_lib = None
+
+
+class SgtaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once; raises SgtaHipError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgtaHipError(
+            "libsgta_hip.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C sgtapose_amd/csrc).  There is no CPU / PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = header / library out of sync: loud
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        kind = "bad argument" if rc < 0 else "hipError_t"
+        raise SgtaHipError("%s failed: %s %d" % (name, kind, rc))
+    return rc

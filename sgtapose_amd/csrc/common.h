@@ -1,0 +1,32 @@
+// Shared device/host helpers for libsgta_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SGTA_OK 0
+#define SGTA_EBADARG (-1)
+
+// launch-site error check: returns hipError_t (>0) from the enclosing extern "C" entry point
+#define SGTA_LAUNCH_CHECK()                         \
+  do {                                              \
+    hipError_t e__ = hipGetLastError();             \
+    if (e__ != hipSuccess) return (int)e__;         \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware 1-D block remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
+// Logical ids are laid out so that ``inner`` consecutive logical ids (e.g. the cout tiles of one
+// pixel tile) run back-to-back on ONE XCD and hit its L2.  Bijective for any (n_outer, inner);
+// logical id >= n_outer*inner means "no work".
+__device__ __forceinline__ void xcd_remap(int bid, int inner, int& outer_id, int& inner_id) {
+  int xcd = bid & 7;
+  int slot = bid >> 3;
+  inner_id = slot % inner;
+  outer_id = (slot / inner) * 8 + xcd;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }

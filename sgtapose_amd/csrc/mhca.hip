@@ -1,0 +1,133 @@
+// Fused multi-head cross-attention core with the learned structure-prior bias (gfx950).
+//   out[b,i,h*d:(h+1)*d] = softmax_j( Q[b,i,h]*K[b,j,h] / sqrt(d) + pos_embed[h,i,j] ) . V[b,j,h]
+// = the energy / softmax / AV part of MHCA_ein.forward (reference dla.py:874-885); the Q/K/V and
+// fc projections are token GEMMs (linear.hip).  The [B,8,n,n] energy tensor of the reference never
+// exists: scores live in MFMA accumulators, softmax is online (running max / sum), and P feeds the
+// PV product straight from registers.
+//
+// Mapping (v_mfma_f32_16x16x4_f32, exact f32):
+//   S^T tile (16 keys x 16 queries) = Kt-tile . Q^T : the QUERY is on the lane (col = lane&15), a
+//   lane holds 4 keys (j = 4*(lane>>4)+r) -> the softmax row statistics need 2 shuffles per tile,
+//   and the accumulator registers ARE the B operand of the PV product O^T[d, i] += V^T[d, j] P^T[j, i]
+//   (k index = lane>>4) with no data movement.  Head dims 4/8/16 only fill 4/8/16 of the 16 MFMA
+//   rows of PV; that padding is inherent to the reference's tiny heads.
+// K and V of one (batch, head) are staged once, transposed, in LDS ([d][n_pad], <= 38 KiB) and
+// shared by the work-group's 4 waves, each of which walks its own 16-query tiles over all keys.
+#include "common.h"
+
+template <int D>
+__global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, int ldq,
+                                                   const float* __restrict__ k, int ldk,
+                                                   const float* __restrict__ v, int ldv,
+                                                   const float* __restrict__ pos,
+                                                   float* __restrict__ out, int ldo, int n, int npad,
+                                                   float inv_scale) {
+  extern __shared__ float smem[];
+  const int ldt = npad + 4;                        // keeps 16-B alignment of the b128 V reads
+  float* Kt = smem;                                // [D][ldt]
+  float* Vt = smem + D * ldt;                      // [D][ldt]
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+
+  // ---- stage K^T, V^T of (b, h) -----------------------------------------------------------------
+  for (int t = tid; t < npad * (D / 4); t += 256) {
+    int j = t % npad, c4 = t / npad;
+    f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (j < n) {
+      kv = *reinterpret_cast<const f32x4*>(k + ((long)b * n + j) * ldk + h * D + c4 * 4);
+      vv = *reinterpret_cast<const f32x4*>(v + ((long)b * n + j) * ldv + h * D + c4 * 4);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Kt[(c4 * 4 + c) * ldt + j] = kv[c];
+      Vt[(c4 * 4 + c) * ldt + j] = vv[c];
+    }
+  }
+  __syncthreads();
+
+  const int ntile = npad / 16;
+  const float* posh = pos ? pos + (long)h * n * n : nullptr;
+  const int vrow = (li < D ? li : D - 1) * ldt;    // MFMA rows >= D are never read back
+
+  for (int it = blockIdx.x * 4 + wave; it < ntile; it += gridDim.x * 4) {
+    const int i = it * 16 + li;
+    const int ic = i < n ? i : n - 1;
+    // Q fragment: B[k = g][col = li] = Q[i][h*D + 4c + g]
+    float qf[D / 4];
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) qf[c] = q[((long)b * n + ic) * ldq + h * D + c * 4 + g];
+    const float* prow = posh ? posh + (long)ic * n : nullptr;
+
+    float m = -INFINITY, lsum = 0.0f;
+    f32x4 o = {0, 0, 0, 0};
+    float bias[4], bias_nx[4];
+    auto load_bias = [&](int jt, float* dst) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int j = jt * 16 + 4 * g + r;
+        dst[r] = (j < n) ? (prow ? prow[j] : 0.0f) : -INFINITY;
+      }
+    };
+    load_bias(0, bias);
+    for (int jt = 0; jt < ntile; ++jt) {
+      if (jt + 1 < ntile) load_bias(jt + 1, bias_nx);
+      f32x4 s = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < D / 4; ++c) {
+        float a = Kt[(c * 4 + g) * ldt + jt * 16 + li];     // A[row = key li][k = g]
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf[c], s, 0, 0, 0);
+      }
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], inv_scale, bias[r]);
+      float tmax = fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3]));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float mn = fmaxf(m, tmax);
+      const float alpha = __expf(m - mn);
+      m = mn;
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = __expf(e[r] - mn);
+      lsum = fmaf(lsum, alpha, (p[0] + p[1]) + (p[2] + p[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] *= alpha;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(&Vt[vrow + jt * 16 + 4 * g]);  // V[j=4g+r][dd=li]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r], p[r], o, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[r] = bias_nx[r];
+    }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    // O^T rows dd = 4g + r live in lanes with 4g < D
+    if (i < n && 4 * g < D) {
+      const float inv = 1.0f / lsum;
+      f32x4 r4 = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+      *reinterpret_cast<f32x4*>(out + ((long)b * n + i) * ldo + h * D + 4 * g) = r4;
+    }
+  }
+}
+
+extern "C" int sgta_mhca_fwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v,
+                                 int ldv, const float* pos_embed, float* out, int ldo, int B, int n,
+                                 int n_heads, int head_dim, hipStream_t st) {
+  if (!q || !k || !v || !out || B <= 0 || n <= 0 || n_heads <= 0) return SGTA_EBADARG;
+  if ((ldq | ldk | ldv | ldo) & 3) return SGTA_EBADARG;
+  const int npad = (n + 15) / 16 * 16;
+  const int ntile = npad / 16;
+  int qsplit = (ntile + 3) / 4;                    // work-groups along the query axis
+  if (qsplit > 8) qsplit = 8;
+  dim3 grid(qsplit, n_heads, B);
+  const float inv = 1.0f / sqrtf((float)head_dim);
+  size_t lds = (size_t)2 * head_dim * (npad + 4) * sizeof(float);
+  switch (head_dim) {
+    case 4: hipLaunchKernelGGL(mhca_kernel<4>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, out, ldo, n, npad, inv); break;
+    case 8: hipLaunchKernelGGL(mhca_kernel<8>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, out, ldo, n, npad, inv); break;
+    case 16: hipLaunchKernelGGL(mhca_kernel<16>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, out, ldo, n, npad, inv); break;
+    default: return SGTA_EBADARG;
+  }
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}

@@ -1,0 +1,265 @@
+"""Python faces of the C-ABI entry points: torch tensors in, device pointers out to libsgta_hip.so.
+
+torch is plumbing only (device memory + the current HIP stream); every function below enqueues
+hand-written HIP kernels and raises if the library is missing (sgtapose_amd/_lib.py).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype=torch.float32):
+    if not (t.is_cuda and t.dtype == dtype):
+        raise _lib.SgtaHipError("expected a %s tensor on the GPU, got %s on %s" % (dtype, t.dtype, t.device))
+    return t
+
+
+class View:
+    """A [B, C, H, W] float32 activation that may be a channel slice of a wider buffer."""
+    __slots__ = ("base", "c0", "C")
+
+    def __init__(self, base, c0=0, C=None):
+        self.base = _req(base)
+        assert base.is_contiguous() and base.dim() == 4
+        self.c0 = c0
+        self.C = base.shape[1] - c0 if C is None else C
+        assert 0 <= c0 and c0 + self.C <= base.shape[1]
+
+    @property
+    def B(self):
+        return self.base.shape[0]
+
+    @property
+    def H(self):
+        return self.base.shape[2]
+
+    @property
+    def W(self):
+        return self.base.shape[3]
+
+    @property
+    def ptr(self):
+        return self.base.data_ptr() + 4 * self.c0 * self.H * self.W
+
+    @property
+    def bs(self):
+        return self.base.shape[1] * self.H * self.W
+
+    def tensor(self):
+        return self.base[:, self.c0:self.c0 + self.C]
+
+    def slice(self, c0, C):
+        return View(self.base, self.c0 + c0, C)
+
+
+def as_view(t):
+    return t if isinstance(t, View) else View(t.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing (host side, once per model): BN folding + the layouts the kernels read
+# ---------------------------------------------------------------------------------------------
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def fold_bn(weight, bias, bn, eps=1e-5):
+    """Return (weight * s[co], shift) for conv -> BatchNorm(eval);  bn = (gamma, beta, mean, var) or None."""
+    co = weight.shape[0]
+    b = bias if bias is not None else torch.zeros(co, dtype=weight.dtype, device=weight.device)
+    if bn is None:
+        return weight, b
+    gamma, beta, mean, var = bn
+    s = gamma / torch.sqrt(var + eps)
+    return weight * s.view(-1, *([1] * (weight.dim() - 1))), (b - mean) * s + beta
+
+
+class PackedConv:
+    """Packed weights of one conv / DCN main GEMM: wt [Kpad][Cout_pad], bias [Cout_pad]."""
+
+    def __init__(self, weight, bias=None, bn=None, stride=1, pad=None, tap_major=False):
+        w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
+        co, ci, kh, kw = w.shape
+        assert kh == kw
+        self.Cout, self.Cin, self.ks, self.stride = co, ci, kh, stride
+        self.pad = kh // 2 if pad is None else pad
+        K = ci * kh * kw
+        self.Kpad, self.Cout_pad = _round_up(K, 16), _round_up(co, 32)
+        if tap_major:                           # DCN: k = tap*Cin + c
+            flat = w.permute(2, 3, 1, 0).reshape(K, co)
+        else:                                   # conv: k = c*ks*ks + tap
+            flat = w.reshape(co, K).t()
+        wt = torch.zeros(self.Kpad, self.Cout_pad, dtype=torch.float32, device=w.device)
+        wt[:K, :co] = flat
+        bb = torch.zeros(self.Cout_pad, dtype=torch.float32, device=w.device)
+        bb[:co] = b
+        self.wt, self.bias = wt.contiguous(), bb.contiguous()
+
+    def flops(self, M):
+        return 2.0 * M * self.Cout * self.Cin * self.ks * self.ks
+
+
+def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
+    """out = act(conv(x) + bias [+ res]) ; x/out/res are Views (or contiguous tensors)."""
+    x, out = as_view(x), as_view(out)
+    assert x.C == pc.Cin and out.C == pc.Cout and out.B == x.B
+    rp, rbs = None, 0
+    if res is not None:
+        res = as_view(res)
+        assert res_mode in (1, 2) and res.C == pc.Cout and res.H == out.H and res.W == out.W
+        rp, rbs = res.ptr, res.bs
+    _lib.call("sgta_conv2d_f32", x.ptr, x.bs, pc.wt.data_ptr(), pc.bias.data_ptr(), rp, rbs, out.ptr,
+              out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, pc.Kpad, pc.ks, pc.stride, pc.pad,
+              act, res_mode if res is not None else 0, tile, _stream())
+    return out
+
+
+def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
+    """Fused modulated deformable conv: ``om`` is the raw 27-channel offset/mask conv output."""
+    x, om, out = as_view(x), as_view(om), as_view(out)
+    assert om.C == 27 and x.C == pc.Cin and out.C == pc.Cout
+    _lib.call("sgta_dcnv2_fwd_f32", x.ptr, x.bs, om.ptr, om.bs, pc.wt.data_ptr(), pc.bias.data_ptr(),
+              out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act, tile, _stream())
+    return out
+
+
+def maxpool2(x, out):
+    x, out = as_view(x), as_view(out)
+    _lib.call("sgta_maxpool2_f32", x.ptr, x.bs, out.ptr, out.bs, x.B, x.C, x.H, x.W, _stream())
+    return out
+
+
+def upsample_add(x, w, skip, out, f):
+    x, out = as_view(x), as_view(out)
+    sp, sbs = None, 0
+    if skip is not None:
+        skip = as_view(skip)
+        sp, sbs = skip.ptr, skip.bs
+    _lib.call("sgta_upsample_add_f32", x.ptr, x.bs, _req(w).data_ptr(), sp, sbs, out.ptr, out.bs, x.B,
+              x.C, x.H, x.W, f, _stream())
+    return out
+
+
+def sigmoid_(t):
+    _req(t)
+    assert t.is_contiguous()
+    _lib.call("sgta_sigmoid_f32", t.data_ptr(), t.data_ptr(), t.numel(), _stream())
+    return t
+
+
+def prior_argmax(pre_cls, cur_cls, out=None):
+    B, K, h, w = pre_cls.shape
+    out = torch.empty(2, B, K, 2, dtype=torch.float32, device=pre_cls.device) if out is None else out
+    _lib.call("sgta_prior_argmax", _req(pre_cls.contiguous()).data_ptr(), _req(cur_cls.contiguous()).data_ptr(),
+              out.data_ptr(), B, K, h, w, _stream())
+    return out
+
+
+def window_index(idx_xy, scale, ks, H, W, fid=None, win=None):
+    _, B, K, _ = idx_xy.shape
+    n = K * (1 + 2 * (ks // 2)) ** 2
+    fid = torch.empty(2, B, n, dtype=torch.int64, device=idx_xy.device) if fid is None else fid
+    win = torch.empty(B, n, dtype=torch.uint8, device=idx_xy.device) if win is None else win
+    _lib.call("sgta_window_index", idx_xy.data_ptr(), fid.data_ptr(), win.data_ptr(), B, K,
+              ctypes.c_float(scale), ks, H, W, _stream())
+    return fid, win
+
+
+def window_gather(feats, fid, tok, col0=0):
+    feats = as_view(feats)
+    B, n = fid.shape
+    ld = tok.shape[-1]
+    _lib.call("sgta_window_gather", feats.ptr, feats.bs, fid.data_ptr(), tok.data_ptr(), B, feats.C,
+              feats.H, feats.W, n, ld, col0, _stream())
+    return tok
+
+
+def window_scatter(tok, fid, win, feats):
+    feats = as_view(feats)
+    B, n = fid.shape
+    assert tok.is_contiguous() and tok.shape[-1] == feats.C
+    _lib.call("sgta_window_scatter", tok.data_ptr(), fid.data_ptr(), win.data_ptr(), feats.ptr, feats.bs,
+              B, feats.C, feats.H, feats.W, n, _stream())
+    return feats
+
+
+def linear(x, w, bias, out, relu=False, res=None, ln=None, K=None):
+    """out[M,N] = LN?(relu?(x[:, :K] @ w.T + bias) + res); x/out/res are 2-D row-major (last dim = ld)."""
+    M = x.shape[0]
+    N, Kw = w.shape
+    K = Kw if K is None else K
+    assert x.stride(-1) == 1 and out.stride(-1) == 1 and w.is_contiguous()
+    g, bt = (ln[0].data_ptr(), ln[1].data_ptr()) if ln is not None else (None, None)
+    rp, ldr = (res.data_ptr(), res.stride(0)) if res is not None else (None, 0)
+    _lib.call("sgta_linear_f32", x.data_ptr(), x.stride(0), w.data_ptr(),
+              None if bias is None else bias.data_ptr(), rp, ldr, g, bt, out.data_ptr(), out.stride(0),
+              M, N, K, int(relu), _stream())
+    return out
+
+
+def mhca(q, k, v, pos, out, B, n, n_heads, head_dim):
+    """q/k/v/out: 2-D [B*n, ld] row-major views (column slices allowed)."""
+    _lib.call("sgta_mhca_fwd_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+              v.stride(0), None if pos is None else pos.data_ptr(), out.data_ptr(), out.stride(0), B, n,
+              n_heads, head_dim, _stream())
+    return out
+
+
+_GAUSS = {}
+
+
+def gauss_taps(device):
+    """The 13 float64 taps (far .. centre) of scipy's sigma=3, truncate=4 kernel, computed on the
+    host exactly as scipy does (exp in float64, normalised by the float64 sum)."""
+    key = str(device)
+    if key not in _GAUSS:
+        x = np.arange(-12, 13)
+        phi = np.exp(-0.5 / 9.0 * x ** 2)
+        phi = phi / phi.sum()
+        _GAUSS[key] = torch.from_numpy(phi[:13].copy()).to(device)
+    return _GAUSS[key]
+
+
+def peaks_decode(hm, reg=None, tracking=None, ws=None):
+    """hm [B,K,H,W] post-sigmoid.  Returns dict(scores, xs, ys, regs, trks, npeaks) of device tensors."""
+    _req(hm)
+    B, K, H, W = hm.shape
+    dev = hm.device
+    hm = hm.contiguous()
+    if ws is None:
+        ws = (torch.empty_like(hm), torch.empty_like(hm))
+    out = dict(scores=torch.empty(B, K, dtype=torch.float32, device=dev),
+               xs=torch.empty(B, K, dtype=torch.int64, device=dev),
+               ys=torch.empty(B, K, dtype=torch.int64, device=dev),
+               regs=torch.zeros(B, K, 2, dtype=torch.float32, device=dev),
+               trks=torch.zeros(B, K, 2, dtype=torch.float32, device=dev),
+               npeaks=torch.empty(B, K, dtype=torch.int32, device=dev))
+    _lib.call("sgta_peaks_decode", hm.data_ptr(), None if reg is None else _req(reg.contiguous()).data_ptr(),
+              None if tracking is None else _req(tracking.contiguous()).data_ptr(),
+              gauss_taps(dev).data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), out["scores"].data_ptr(),
+              out["xs"].data_ptr(), out["ys"].data_ptr(), out["regs"].data_ptr(), out["trks"].data_ptr(),
+              out["npeaks"].data_ptr(), B, K, H, W, _stream())
+    return out
+
+
+def soft_argmax(hm, beta=25.0, size_mult=1.0):
+    _req(hm)
+    B, K, H, W = hm.shape
+    out = torch.empty(B, K, 2, dtype=torch.float32, device=hm.device)
+    _lib.call("sgta_softargmax", hm.contiguous().data_ptr(), out.data_ptr(), B, K, H, W,
+              ctypes.c_float(beta), ctypes.c_float(size_mult), _stream())
+    return out
+
+
+def head_scale(head_dim):
+    return 1.0 / math.sqrt(head_dim)

@@ -1,0 +1,297 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the golden vectors
+generated from the reference.  Integer / index outputs must be bit-exact; floating point within the
+north-star tolerance of 1e-3 abs (most kernels are asserted much tighter)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+import oracle
+from oracle import temporal as T
+from util import ARGS, golden, golden_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sgtapose_amd import _lib, ops as _ops
+    _lib.load()
+    assert _lib.call("sgta_check_device") == 0
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def model():
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
+    m.load_state_dict(golden_state_dict(0), strict=True)
+    return m.to(DEV).eval()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,ks,stride,tile", [
+    (3, 16, 7, 1, 0), (1, 16, 7, 1, 1), (16, 16, 3, 1, 0), (16, 32, 3, 2, 0), (32, 64, 1, 1, 2),
+    (64, 64, 3, 1, 2), (64, 64, 3, 1, 1), (64, 128, 3, 2, 3), (128, 128, 3, 1, 3), (128, 128, 3, 1, 2),
+    (448, 128, 1, 1, 0), (64, 27, 3, 1, 0), (64, 768, 3, 1, 0), (256, 7, 1, 1, 0)])
+def test_conv2d_bn_relu_residual(ops, cin, cout, ks, stride, tile):
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    B, H, W = 3, 24, 40
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    bn = (torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1,
+          torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5)
+    ref = F.batch_norm(F.conv2d(x, w, None, stride, ks // 2), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    res = torch.randn(ref.shape, generator=g)
+    pc = ops.PackedConv(w.to(DEV), None, tuple(v.to(DEV) for v in bn), stride=stride)
+    out = torch.empty(ref.shape, device=DEV)
+    ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU, res=res.to(DEV), res_mode=1, tile=tile)
+    assert torch.allclose(out.cpu(), F.relu(ref + res), atol=2e-5, rtol=1e-5)
+    ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU, res=res.to(DEV), res_mode=2, tile=tile)
+    assert torch.allclose(out.cpu(), F.relu(ref) + res, atol=2e-5, rtol=1e-5)
+    ops.conv2d(x.to(DEV), pc, out, ops.ACT_SIGMOID, tile=tile)
+    assert torch.allclose(out.cpu(), torch.sigmoid(ref), atol=2e-5, rtol=1e-5)
+
+
+def test_conv2d_channel_slice_views(ops):
+    """input / output / residual as channel slices of wider (concat) buffers, batch > 1."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 16, 24
+    big_in = torch.randn(B, 96, H, W, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24
+    pc = ops.PackedConv(w.to(DEV), torch.randn(32, generator=g).to(DEV))
+    big_out = torch.zeros(B, 80, H, W, device=DEV)
+    vin = ops.View(big_in.to(DEV), 16, 64)
+    vout = ops.View(big_out, 40, 32)
+    ops.conv2d(vin, pc, vout, ops.ACT_NONE)
+    ref = F.conv2d(big_in[:, 16:80], w, pc.bias[:32].cpu(), padding=1)
+    assert torch.allclose(big_out[:, 40:72].cpu(), ref, atol=2e-5, rtol=1e-5)
+    assert float(big_out[:, :40].abs().sum()) == 0 and float(big_out[:, 72:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("cin,cout,H,W,tile,off_scale", [
+    (64, 64, 24, 40, 2, 1.5), (64, 64, 24, 40, 1, 1.5), (128, 64, 12, 20, 0, 3.0), (512, 256, 6, 10, 3, 1.0),
+    (256, 128, 9, 14, 2, 8.0), (16, 16, 8, 8, 0, 0.0)])
+def test_dcnv2_matches_oracle(ops, cin, cout, H, W, tile, off_scale):
+    g = torch.Generator().manual_seed(cin + cout + H)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    omw = torch.randn(27, cin, 3, 3, generator=g) * (off_scale / (cin * 9) ** 0.5)
+    omb = torch.randn(27, generator=g) * 0.2
+    ref = oracle.dcn_v2_forward(x, w, b, omw, omb)
+    pc_om = ops.PackedConv(omw.to(DEV), omb.to(DEV))
+    pc = ops.PackedConv(w.to(DEV), b.to(DEV), tap_major=True)
+    om = torch.empty(B, 27, H, W, device=DEV)
+    out = torch.empty(B, cout, H, W, device=DEV)
+    xd = x.to(DEV)
+    ops.conv2d(xd, pc_om, om)
+    assert torch.allclose(om.cpu(), F.conv2d(x, omw, omb, padding=1), atol=2e-5, rtol=1e-5)
+    ops.dcn_v2(xd, om, pc, out, tile=tile)
+    assert torch.allclose(out.cpu(), ref, atol=5e-5, rtol=1e-4)
+
+
+def test_dcn_module_zero_init_is_half_conv(ops):
+    """Known answer: zero offset/mask conv -> 0.5 * conv3x3(x) + bias."""
+    from sgtapose_amd.dcn_v2 import DCN
+    torch.manual_seed(0)
+    d = DCN(32, 48, (3, 3), 1, 1).to(DEV)
+    x = torch.randn(2, 32, 10, 12, device=DEV)
+    with torch.no_grad():
+        d.bias.uniform_(-1, 1)
+        y = d(x)
+        ref = 0.5 * F.conv2d(x.cpu(), d.weight.cpu(), None, padding=1) + d.bias.cpu().view(1, -1, 1, 1)
+    assert torch.allclose(y.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
+def test_maxpool_and_upsample_add(ops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 24, 12, 20, generator=g)
+    out = torch.empty(2, 24, 6, 10, device=DEV)
+    ops.maxpool2(x.to(DEV), out)
+    assert torch.equal(out.cpu(), F.max_pool2d(x, 2, 2))
+    for f in (2, 4):
+        w = torch.rand(24, 1, 2 * f, 2 * f, generator=g)
+        skip = torch.randn(2, 24, 12 * f, 20 * f, generator=g)
+        ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=24) + skip
+        o = torch.empty(ref.shape, device=DEV)
+        ops.upsample_add(x.to(DEV), w.to(DEV), skip.to(DEV), o, f)
+        assert torch.allclose(o.cpu(), ref, atol=1e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_window_index_gather_scatter_match_reference(ops):
+    g = golden("window_ops.npz")
+    case = cases.window_case()
+    idx = ops.prior_argmax(case["pre_cls"].to(DEV), case["cur_cls"].to(DEV))
+    assert torch.equal(idx[0].cpu(), t(g["pre_idx"])) and torch.equal(idx[1].cpu(), t(g["cur_idx"]))
+    sd = golden_state_dict()
+    for i, (pre_f, cur_f, tok) in enumerate(case["levels"]):
+        B, C, H, W = cur_f.shape
+        fid, win = ops.window_index(idx, float(cases.LEVEL_SCALE[i]), cases.LEVEL_KS[i], H, W)
+        assert torch.equal(fid[0].cpu(), t(g["pre_fid%d" % i])), "pre fid level %d" % i
+        assert torch.equal(fid[1].cpu(), t(g["cur_fid%d" % i])), "cur fid level %d" % i
+        n = fid.shape[2]
+        key = torch.empty(B * n, C, device=DEV)
+        ops.window_gather(pre_f.to(DEV), fid[0], key)
+        assert torch.equal(key.view(B, n, C).cpu(), t(g["key%d" % i]))
+        # cat-MLP + ordered scatter, exactly as the engine does it
+        cat_tok = torch.empty(B * n, 2 * C, device=DEV)
+        cur_d = cur_f.to(DEV).clone()
+        cat_tok[:, :C] = tok.to(DEV).view(B * n, C)
+        ops.window_gather(cur_d, fid[1], cat_tok, col0=C)
+        w0, b0 = sd["cat_layer.%d.0.weight" % i].to(DEV), sd["cat_layer.%d.0.bias" % i].to(DEV)
+        w2, b2 = sd["cat_layer.%d.2.weight" % i].to(DEV), sd["cat_layer.%d.2.bias" % i].to(DEV)
+        h1 = ops.linear(cat_tok, w0, b0, torch.empty(B * n, 4 * C, device=DEV), relu=True)
+        z = ops.linear(h1, w2, b2, torch.empty(B * n, C, device=DEV))
+        ops.window_scatter(z, fid[1], win, cur_d)
+        got = T.window_gather(cur_d.cpu(), fid[1].cpu())
+        assert torch.allclose(got, t(g["sub_tok%d" % i]), atol=1e-4, rtol=1e-4), "substitute level %d" % i
+        untouched = torch.ones(B, H * W, dtype=torch.bool).scatter_(1, fid[1].cpu(), False)
+        same = (cur_d.cpu() == cur_f).reshape(B, C, -1).all(1)
+        assert bool(same[untouched].all())
+    # non-square: both axes clamp to H-1
+    idn = ops.prior_argmax(case["ns_cls"].to(DEV), case["ns_cls"].to(DEV))
+    f1, _ = ops.window_index(idn, 1.0, 3, 24, 40)
+    f2, _ = ops.window_index(idn, 0.5, 1, 12, 20)
+    assert torch.equal(f1[0].cpu(), t(g["ns_fid"])) and torch.equal(f2[0].cpu(), t(g["ns_fid2"]))
+
+
+def test_linear_with_relu_residual_layernorm(ops):
+    g = torch.Generator().manual_seed(9)
+    for (M, N, K, ln) in ((300, 64, 128, True), (77, 16, 1024, True), (1183, 1024, 16, False), (224, 2048, 1024, False),
+                          (130, 32, 64, True)):
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = F.linear(x, w, b)
+        out = torch.empty(M, N, device=DEV)
+        ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), out, relu=True)
+        assert torch.allclose(out.cpu(), F.relu(ref), atol=3e-5, rtol=1e-5)
+        if ln:
+            gm, bt = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+            ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), out, res=r.to(DEV), ln=(gm.to(DEV), bt.to(DEV)))
+            assert torch.allclose(out.cpu(), F.layer_norm(ref + r, (N,), gm, bt, 1e-5), atol=5e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("i", [2, 1, 0])
+def test_attention_and_encoder_match_reference(ops, model, i):
+    g = golden("encoder_ops.npz")
+    q, k = cases.encoder_case()[i]
+    B, n, C = q.shape
+    eng = model.engine()
+    Tf = eng.tf[i]
+    hid = Tf["hid"]
+    M = B * n
+    qd, kd = q.to(DEV).view(M, C), k.to(DEV).view(M, C)
+    kv = ops.linear(kd, Tf["wkv"], None, torch.empty(M, 2 * hid, device=DEV))
+    qq = ops.linear(qd, Tf["wq"], None, torch.empty(M, hid, device=DEV))
+    att = ops.mhca(qq, kv[:, :hid], kv[:, hid:], Tf["pos"], torch.empty(M, hid, device=DEV), B, n, 8, hid // 8)
+    a = ops.linear(att, Tf["fc_w"], Tf["fc_b"], torch.empty(M, C, device=DEV))
+    assert torch.allclose(a.view(B, n, C).cpu(), t(g["mhca%d" % i]), atol=1e-4, rtol=1e-4)
+    cur = qd
+    for it in range(3):
+        ops.linear(cur, Tf["wq"], None, qq)
+        ops.mhca(qq, kv[:, :hid], kv[:, hid:], Tf["pos"], att, B, n, 8, hid // 8)
+        y1 = ops.linear(att, Tf["fc_w"], Tf["fc_b"], torch.empty(M, C, device=DEV), res=cur, ln=Tf["ln1"])
+        hdn = ops.linear(y1, Tf["w1"], Tf["b1"], torch.empty(M, 1024, device=DEV), relu=True)
+        cur = ops.linear(hdn, Tf["w2"], Tf["b2"], torch.empty(M, C, device=DEV), res=y1, ln=Tf["ln3"])
+        if it == 0:
+            assert torch.allclose(cur.view(B, n, C).cpu(), t(g["layer%d" % i]), atol=2e-4, rtol=1e-4)
+    assert torch.allclose(cur.view(B, n, C).cpu(), t(g["enc%d" % i]), atol=5e-4, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_decode_matches_reference_bit_exact(ops):
+    from sgtapose_amd.decode import dream_generic_decode
+    g = golden("decode_ops.npz")
+    hm, reg, trk = cases.decode_case()
+    dets = dream_generic_decode({"hm": hm.to(DEV), "reg": reg.to(DEV), "tracking": trk.to(DEV)}, K=7)
+    for b in range(2):
+        assert list(dets["npeaks"][b].cpu().numpy()) == list(g["peaks_count_%d" % b])
+        for k in ("scores", "clses", "xs", "ys", "cts", "cts_wreg", "regs", "tracking"):
+            ref = g["det%d_%s" % (b, k)]
+            got = dets[k][b:b + 1].cpu().numpy()
+            assert got.shape == ref.shape and got.dtype == ref.dtype, k
+            assert np.array_equal(got, ref), k
+    sa = ops.soft_argmax(hm.to(DEV))
+    assert torch.allclose(sa.cpu(), t(g["softargmax"]), atol=1e-3)
+
+
+def test_gaussian_filter_bit_exact_vs_scipy(ops):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.RandomState(1)
+    for shape in ((1, 2, 120, 160), (2, 1, 15, 9), (1, 1, 30, 7)):
+        m = torch.from_numpy(rng.rand(*shape).astype(np.float32))
+        ws = (torch.empty(shape, device=DEV), torch.empty(shape, device=DEV))
+        ops.peaks_decode(m.to(DEV), ws=ws)
+        got = ws[1].cpu().numpy()
+        for b in range(shape[0]):
+            for k in range(shape[1]):
+                assert np.array_equal(got[b, k], gaussian_filter(m[b, k].numpy(), sigma=3))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["128", "128_first", "96x160", "480", "480x640"])
+def test_fullnet_matches_reference(model, tag):
+    from sgtapose_amd.synthetic import make_inputs
+    g = golden("fullnet_%s.npz" % tag)
+    B, H, W, seed, first = [int(v) for v in g["meta"]]
+    inp = make_inputs(B, H, W, seed=seed, first_frame=bool(first))
+    out = model(*[inp[k].to(DEV) for k in ARGS])[-1]
+    assert sorted(out) == ["hm", "reg", "tracking"]
+    if "feat" in g.files:
+        feat = model.engine().last_feat.tensor().cpu()
+        assert torch.allclose(feat, t(g["feat"]), atol=1e-3), float((feat - t(g["feat"])).abs().max())
+        assert torch.equal(model.engine().last_fid0[0].cpu(), t(g["pre_fid0"]))
+        assert torch.equal(model.engine().last_fid0[1].cpu(), t(g["cur_fid0"]))
+    for k, ref in (("hm", "hm_logits"), ("reg", "reg"), ("tracking", "tracking")):
+        err = float((out[k].cpu() - t(g[ref])).abs().max())
+        assert out[k].shape == g[ref].shape and out[k].dtype == torch.float32
+        assert err < 1e-3, (k, err)
+
+
+def test_skipping_dead_levels_changes_nothing(model):
+    from sgtapose_amd.synthetic import make_inputs
+    inp = make_inputs(2, 128, 128, seed=317)
+    dev = [inp[k].to(DEV) for k in ARGS]
+    eng = model.engine()
+    a = {k: v.clone() for k, v in model(*dev)[-1].items()}
+    eng.compute_dead_levels = False
+    try:
+        b = model(*dev)[-1]
+    finally:
+        eng.compute_dead_levels = True
+    for k in a:
+        assert torch.equal(a[k], b[k])
+
+
+def test_process_contract_and_keypoints_on_peaked_maps(model):
+    """SGTADetector.process contract for B>1 + decode parity on peaked maps (random-init logits are flat)."""
+    from sgtapose_amd.decode import dream_generic_decode
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs, peaked_heatmaps
+    inp = make_inputs(3, 128, 160, seed=5)
+    dev = [inp[k].to(DEV) for k in ARGS]
+    det = BatchedDetector(model)
+    output, dets = det.process(*dev[:4], pre_hms_cls=dev[4], repro_hms_cls=dev[5])
+    sd = golden_state_dict()
+    ref_out, ref_dets = oracle.process_reference(sd, *[inp[k] for k in ARGS])
+    assert torch.allclose(output["hm"].cpu(), ref_out["hm"], atol=1e-3)
+    assert dets["scores"].shape == (3, 7) and dets["cts_wreg"].shape == (3, 7, 2, 1)
+    # keypoint parity on peaked maps fed to both decoders
+    hm, _ = peaked_heatmaps(3, 32, 40, seed=2)
+    o = {"hm": hm.to(DEV), "reg": output["reg"], "tracking": output["tracking"]}
+    got = dream_generic_decode(o, K=7)
+    ref = oracle.dream_decode({"hm": hm, "reg": output["reg"].cpu(), "tracking": output["tracking"].cpu()})
+    assert torch.equal(got["xs"].cpu(), ref["xs"]) and torch.equal(got["ys"].cpu(), ref["ys"])
+    assert torch.equal(got["cts_wreg"].cpu(), ref["cts_wreg"])
+    assert int((got["scores"] > 0).sum()) == 21
