@@ -39,22 +39,33 @@ int sgta_check_device(void);
  * the DCN offset/mask conv and the heads:
  *   sgtapose/lib/model/networks/dla.py:41-69, :157-175, :178-231, :259-270, :302-312;
  *   sgtapose/lib/model/networks/base_model.py:121-135.
- * wt   : packed weights [Kpad][Cout_pad], Kpad = roundup(Cin*ks*ks, 16), Cout_pad = roundup(Cout, 32),
- *        wt[(c*ks*ks + ky*ks + kx) * Cout_pad + co] = W[co][c][ky][kx] * bn_scale[co], zero padded
- * bias : [Cout_pad] (BatchNorm shift / conv bias) or NULL
+ * wt   : packed weights [Kpad/16][Cout_pad][16], Kpad = roundup(Cin*ks*ks, 16), Cout_pad = roundup(Cout, 32),
+ *        element (k/16, co, k%16) = W[co][c][ky][kx] * bn_scale[co] with k = c*ks*ks + ky*ks + kx, zero padded
+ * bias : [Cout_pad] (BatchNorm shift / conv bias, zero padded)
+ * ktab : int32 [Kpad][2] = {c*H*W + ky*W + kx, ky*ks + kx} per k; second field 63 for the K padding
  * res  : tensor with y's geometry added before (res_mode 1) or after (res_mode 2) the activation
  * ks in {1,3,7}; tile 0 = auto (1: 32x256, 2: 64x256, 3: 128x128 couts x pixels per work-group). */
-int sgta_conv2d_f32(const float* x, long x_bs, const float* wt, const float* bias, const float* res,
-                    long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
-                    int Cout_pad, int Kpad, int ks, int stride, int pad, int act, int res_mode,
-                    int tile, sgta_stream_t stream);
+int sgta_conv2d_f32(const float* x, long x_bs, const float* wt, const float* bias, const int* ktab,
+                    const float* res, long res_bs, float* y, long y_bs, int B, int Cin, int H, int W,
+                    int Cout, int Cout_pad, int Kpad, int ks, int stride, int pad, int act,
+                    int res_mode, int tile, sgta_stream_t stream);
+
+/* Same contract as sgta_conv2d_f32 for the dominant shape ks=3, stride=1, pad=1 (Cin % 4 == 0): the
+ * contiguous input range covering all nine taps of a run of output pixels is staged in LDS with
+ * coalesced loads and the im2col operand is read from LDS (no global gathers).
+ * wt : packed [Cin/4][Cout_pad][36], element (c/4, co, (c%4)*9 + ky*3 + kx) = W[co][c][ky][kx]*bn_scale[co].
+ * Returns SGTA_EBADARG when (W, tile) is outside the staged-range capacity (W <= 191 for tile 3,
+ * <= 255 for tile 2, <= 767 for tile 1); callers then use sgta_conv2d_f32. */
+int sgta_conv3x3s1_f32(const float* x, long x_bs, const float* wt, const float* bias, const float* res,
+                       long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
+                       int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
 
 /* Modulated deformable 3x3 conv v2 (stride 1, pad 1, dil 1, 1 deformable group) + folded BN + act,
  * gather fused into the GEMM (no column buffer).  Replaces the external lbin/DCNv2 ``dcn_v2_conv``
  * (import dla.py:21-25, constructed dla.py:545, called dla.py:548) and DeformConv's BN+ReLU
  * (dla.py:541-550).  ``om`` is the RAW 27-channel output of conv_offset_mask (channels 2k / 2k+1 =
  * dy / dx of tap k, 18+k = mask logit; the sigmoid is applied here).
- * wt : packed [9*Cin][Cout_pad] with k = tap*Cin + c (tap-major), Cin % 16 == 0. */
+ * wt : packed [9*Cin/16][Cout_pad][16] with k = tap*Cin + c (tap-major), Cin % 16 == 0; act in {0,1}. */
 int sgta_dcnv2_fwd_f32(const float* x, long x_bs, const float* om, long om_bs, const float* wt,
                        const float* bias, float* y, long y_bs, int B, int Cin, int H, int W,
                        int Cout, int Cout_pad, int act, int tile, sgta_stream_t stream);

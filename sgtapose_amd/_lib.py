@@ -17,7 +17,8 @@ _f = ctypes.c_float
 SIGNATURES = {
     "sgta_version": [],
     "sgta_check_device": [],
-    "sgta_conv2d_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_conv2d_f32": [_p, _l, _p, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_conv3x3s1_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_dcnv2_fwd_f32": [_p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_maxpool2_f32": [_p, _l, _p, _l, _i, _i, _i, _i, _p],
     "sgta_upsample_add_f32": [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
@@ -57,8 +58,21 @@ def load():
     return lib
 
 
-def call(name, *args):
-    rc = getattr(load(), name)(*args)
+# When a list, every C-ABI call is bracketed by events on the launch stream and appended as
+# (name, meta, start_event, end_event) -- bench.py's live per-kernel timing (never on by default).
+PROFILE = None
+
+
+def call(name, *args, meta=None):
+    if PROFILE is not None:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        PROFILE.append((name, meta, e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         kind = "bad argument" if rc < 0 else "hipError_t"
         raise SgtaHipError("%s failed: %s %d" % (name, kind, rc))

@@ -91,6 +91,7 @@ class PackedConv:
         w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
         co, ci, kh, kw = w.shape
         assert kh == kw
+        self._w_folded = w
         self.Cout, self.Cin, self.ks, self.stride = co, ci, kh, stride
         self.pad = kh // 2 if pad is None else pad
         K = ci * kh * kw
@@ -101,9 +102,55 @@ class PackedConv:
             flat = w.reshape(co, K).t()
         wt = torch.zeros(self.Kpad, self.Cout_pad, dtype=torch.float32, device=w.device)
         wt[:K, :co] = flat
+        # kernel layout: [K chunk of 16][Cout_pad][16 k] -- one float4 = 4 consecutive k of one cout
+        self.wt = wt.view(self.Kpad // 16, 16, self.Cout_pad).permute(0, 2, 1).contiguous()
         bb = torch.zeros(self.Cout_pad, dtype=torch.float32, device=w.device)
         bb[:co] = b
-        self.wt, self.bias = wt.contiguous(), bb.contiguous()
+        self.bias = bb.contiguous()
+        self.tap_major = tap_major
+        self._ktab = {}
+        # 3x3 / stride 1 / pad 1: second layout for the LDS-patch kernel, [Cin/4][Cout_pad][36]
+        self.wt_patch = None
+        if kh == 3 and stride == 1 and self.pad == 1 and ci % 4 == 0 and not tap_major:
+            wp = torch.zeros(ci // 4, self.Cout_pad, 36, dtype=torch.float32, device=w.device)
+            wp[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
+            self.wt_patch = wp.contiguous()
+
+    def patch_tile(self, W, tile=0, HW=None):
+        """Tile id for sgta_conv3x3s1_f32, or 0 when that kernel does not cover (W, tile)."""
+        if self.wt_patch is None:
+            return 0
+        if tile == 0:
+            # measured (tools/conv_bench.py): 64x256 is the fastest tile whenever it applies; small
+            # maps (level 5: 15x20 per image) waste fewer pixel slots with the 128-pixel tile
+            tile = 2 if self.Cout_pad % 64 == 0 else 1
+            if self.Cout_pad % 128 == 0 and (HW is not None and HW < 1024 or W > 255):
+                tile = 3
+        if tile == 3 and self.Cout_pad % 128:
+            tile = 2
+        if tile == 2 and self.Cout_pad % 64:
+            tile = 1
+        limit = {1: 767, 2: 255, 3: 191}[tile]
+        return tile if W <= limit else 0
+
+    def unpacked(self):
+        """[Kpad, Cout_pad] view of the packed weights (tests)."""
+        return self.wt.permute(0, 2, 1).reshape(self.Kpad, self.Cout_pad)
+
+    def ktab(self, H, W):
+        """int32 [Kpad, 2] = (c*H*W + ky*W + kx, tap) per GEMM k; tap 63 marks the zero padding of K."""
+        key = (H, W)
+        t = self._ktab.get(key)
+        if t is None:
+            K, kk = self.Cin * self.ks * self.ks, self.ks * self.ks
+            k = torch.arange(self.Kpad, dtype=torch.int64)
+            c, tap = k // kk, k % kk
+            off = c * (H * W) + (tap // self.ks) * W + tap % self.ks
+            tab = torch.stack([torch.where(k < K, off, torch.zeros_like(off)),
+                               torch.where(k < K, tap, torch.full_like(tap, 63))], 1)
+            t = tab.to(torch.int32).contiguous().to(self.wt.device)
+            self._ktab[key] = t
+        return t
 
     def flops(self, M):
         return 2.0 * M * self.Cout * self.Cin * self.ks * self.ks
@@ -118,10 +165,36 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         res = as_view(res)
         assert res_mode in (1, 2) and res.C == pc.Cout and res.H == out.H and res.W == out.W
         rp, rbs = res.ptr, res.bs
-    _lib.call("sgta_conv2d_f32", x.ptr, x.bs, pc.wt.data_ptr(), pc.bias.data_ptr(), rp, rbs, out.ptr,
+    pt = pc.patch_tile(x.W, tile, x.H * x.W) if USE_PATCH_KERNEL else 0
+    if pt:
+        _lib.call("sgta_conv3x3s1_f32", x.ptr, x.bs, pc.wt_patch.data_ptr(), pc.bias.data_ptr(), rp, rbs,
+                  out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
+                  res_mode if res is not None else 0, pt, _stream(),
+                  meta=_conv_meta(pc, out, pt, False, patch=True) if _lib.PROFILE is not None else None)
+        return out
+    _lib.call("sgta_conv2d_f32", x.ptr, x.bs, pc.wt.data_ptr(), pc.bias.data_ptr(),
+              pc.ktab(x.H, x.W).data_ptr(), rp, rbs, out.ptr,
               out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, pc.Kpad, pc.ks, pc.stride, pc.pad,
-              act, res_mode if res is not None else 0, tile, _stream())
+              act, res_mode if res is not None else 0, tile, _stream(),
+              meta=_conv_meta(pc, out, tile, False) if _lib.PROFILE is not None else None)
     return out
+
+
+USE_PATCH_KERNEL = True        # tools/tests flip this to time / check the generic implicit-GEMM path
+
+
+def _conv_meta(pc, out, tile, dcn, patch=False):
+    """Algorithmic work of one launch: real (un-padded) MACs and compulsory bytes."""
+    M = out.B * out.H * out.W
+    if tile == 0:
+        tile = 3 if pc.Cout_pad % 128 == 0 else (2 if pc.Cout_pad % 64 == 0 else 1)
+    mt_nt = {1: "1,2", 2: "2,2", 3: "4,1"}[tile]
+    kern = "conv_igemm_kernel<%d,%s,%s>" % (pc.ks, mt_nt, "true" if dcn else "false")
+    if patch:
+        kern = "conv3x3_patch_kernel<%s>" % mt_nt
+    hw_in = M * pc.stride * pc.stride
+    byts = 4.0 * (pc.Cin * hw_in + pc.Cout * M + (27 * M if dcn else 0)) + 4.0 * pc.Cout * pc.Cin * pc.ks ** 2
+    return {"kernel": kern, "flops": pc.flops(M), "bytes": byts}
 
 
 def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
@@ -129,7 +202,8 @@ def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     x, om, out = as_view(x), as_view(om), as_view(out)
     assert om.C == 27 and x.C == pc.Cin and out.C == pc.Cout
     _lib.call("sgta_dcnv2_fwd_f32", x.ptr, x.bs, om.ptr, om.bs, pc.wt.data_ptr(), pc.bias.data_ptr(),
-              out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act, tile, _stream())
+              out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act, tile, _stream(),
+              meta=_conv_meta(pc, out, tile, True) if _lib.PROFILE is not None else None)
     return out
 
 

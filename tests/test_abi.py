@@ -98,13 +98,23 @@ def test_packed_conv_layouts():
     w = torch.randn(5, 3, 3, 3)
     bn = (torch.rand(5) + 0.5, torch.randn(5), torch.randn(5), torch.rand(5) + 0.5)
     pc = PackedConv(w, None, bn, stride=2)
-    assert pc.wt.shape == (32, 32) and pc.Kpad == 32 and pc.Cout_pad == 32
+    assert pc.wt.shape == (2, 32, 16) and pc.Kpad == 32 and pc.Cout_pad == 32
     s = bn[0] / torch.sqrt(bn[3] + 1e-5)
-    assert torch.allclose(pc.wt[:27, :5], (w * s.view(-1, 1, 1, 1)).reshape(5, 27).t())
+    flat = pc.unpacked()
+    assert torch.allclose(flat[:27, :5], (w * s.view(-1, 1, 1, 1)).reshape(5, 27).t())
     assert torch.allclose(pc.bias[:5], bn[1] - bn[2] * s)
-    assert float(pc.wt[27:].abs().sum()) == 0 and float(pc.wt[:, 5:].abs().sum()) == 0
+    assert float(flat[27:].abs().sum()) == 0 and float(flat[:, 5:].abs().sum()) == 0
+    tab = pc.ktab(10, 12)
+    assert tab.shape == (32, 2) and tab.dtype == torch.int32
+    assert tab[13].tolist() == [1 * 120 + 1 * 12 + 1, 4] and tab[27].tolist() == [0, 63]
     pd = PackedConv(torch.randn(4, 16, 3, 3), torch.randn(4), tap_major=True)
-    assert pd.wt.shape == (144, 32)
+    assert pd.wt.shape == (9, 32, 16)
+    wd = pd.unpacked()
+    assert float(wd[2 * 16 + 5, 3]) == float(pd_w(pd, 3, 5, 0, 2))
+
+
+def pd_w(pd, co, c, ky, kx):
+    return pd._w_folded[co, c, ky, kx]
 
 
 def test_dcn_signature_and_guards():
