@@ -70,6 +70,16 @@ int sgta_dcnv2_fwd_f32(const float* x, long x_bs, const float* om, long om_bs, c
                        const float* bias, float* y, long y_bs, int B, int Cin, int H, int W,
                        int Cout, int Cout_pad, int act, int tile, sgta_stream_t stream);
 
+/* Same operator as sgta_dcnv2_fwd_f32, input window staged in LDS: a work-group owns a 2-D tile of 128
+ * pixels (TH x TW), stages the (TH+12) x (TW+12) window of 4 input channels at a time by LDS-DMA
+ * (double buffered) and samples bilinearly from LDS (per-lane global fallback for samples that leave the window,
+ * so the result does not depend on the window size).
+ * wt : packed [Cin/4][Cout_pad][36], element (c/4, co, (c%4)*9 + ky*3 + kx); Cin % 4 == 0, Cout_pad % 64 == 0.
+ * tile = 10*MT + t: MT in {2,4} = 64 / 128 output channels per work-group, t in {0,1,2} = 4x32 / 8x16 / 16x8 tiles. */
+int sgta_dcnv2_lds_f32(const float* x, long x_bs, const float* om, long om_bs, const float* wt,
+                       const float* bias, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
+                       int Cout_pad, int act, int tile, sgta_stream_t stream);
+
 /* MaxPool2d(2,2)  (Tree.downsample, dla.py:209-210, :220). */
 int sgta_maxpool2_f32(const float* x, long x_bs, float* y, long y_bs, int B, int C, int H, int W,
                       sgta_stream_t stream);

@@ -37,6 +37,8 @@ struct ConvArgs {
   int n_ct, n_pt;                  // cout tiles, pixel tiles
 };
 
+struct __attribute__((packed, aligned(4))) F2u { float a, b; };   // 8-byte load at 4-byte alignment
+
 constexpr int BK = 16, LDK = BK + 4;   // 80-B LDS rows: b128 reads and writes are conflict-free
 
 template <int ACT, int RES, int MT, int NT>
@@ -188,20 +190,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
       const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
       const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
       const bool oy0 = y0 >= 0, oy1 = y1 <= a.H - 1, ox0 = x0 >= 0, ox1 = x1 <= a.W - 1;
-      const float w1 = (inside && oy0 && ox0) ? hy * hx : 0.0f;
-      const float w2 = (inside && oy0 && ox1) ? hy * lx : 0.0f;
-      const float w3 = (inside && oy1 && ox0) ? ly * hx : 0.0f;
-      const float w4 = (inside && oy1 && ox1) ? ly * lx : 0.0f;
+      // The two x-corners of a row are adjacent in memory: ONE 8-byte load (4-byte aligned) per row
+      // instead of two 4-byte gathers.  px0 = first element of the pair, clamped so the pair stays
+      // inside the row; wa / wb = the bilinear x-weights routed to the pair's two slots.
+      const float wx0 = (inside && ox0) ? hx : 0.0f, wx1 = (inside && ox1) ? lx : 0.0f;
+      const int px0 = min(max(x0, 0), a.W - 2);
+      const float wa = (x0 == px0 ? wx0 : 0.0f) + (x1 == px0 ? wx1 : 0.0f);
+      const float wb = (x0 == px0 + 1 ? wx0 : 0.0f) + (x1 == px0 + 1 ? wx1 : 0.0f);
+      const float wy0 = oy0 ? hy : 0.0f, wy1 = oy1 ? ly : 0.0f;
+      const float w1 = wy0 * wa, w2 = wy0 * wb, w3 = wy1 * wa, w4 = wy1 * wb;
       const int cy0 = min(max(y0, 0), a.H - 1), cy1 = min(max(y1, 0), a.H - 1);
-      const int cx0 = min(max(x0, 0), a.W - 1), cx1 = min(max(x1, 0), a.W - 1);
-      const int o1 = cy0 * a.W + cx0, o2 = cy0 * a.W + cx1, o3 = cy1 * a.W + cx0, o4 = cy1 * a.W + cx1;
+      const int o1 = cy0 * a.W + px0, o3 = cy1 * a.W + px0;
       const float* xc = xb + (long)c0 * HW;
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
-        float v = w1 * xc[o1];
-        v = fmaf(w2, xc[o2], v);
-        v = fmaf(w3, xc[o3], v);
-        v = fmaf(w4, xc[o4], v);
+        const F2u r0 = *reinterpret_cast<const F2u*>(xc + o1);
+        const F2u r1 = *reinterpret_cast<const F2u*>(xc + o3);
+        float v = w1 * r0.a;
+        v = fmaf(w2, r0.b, v);
+        v = fmaf(w3, r1.a, v);
+        v = fmaf(w4, r1.b, v);
         breg[i] = v * mk;
         xc += HW;
       }
@@ -335,7 +343,7 @@ extern "C" int sgta_dcnv2_fwd_f32(const float* x, long x_bs, const float* om, lo
                                   int Cin, int H, int W, int Cout, int Cout_pad, int act, int tile,
                                   hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SGTA_EBADARG;
-  if (Cin % 16 || Cout_pad % 32 || Cout_pad < Cout || act < 0 || act > 1) return SGTA_EBADARG;
+  if (Cin % 16 || Cout_pad % 32 || Cout_pad < Cout || act < 0 || act > 1 || W < 2) return SGTA_EBADARG;
   ConvArgs a{};
   a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.res = nullptr; a.res_bs = 0;
   a.om = om; a.om_bs = om_bs; a.ktab = nullptr; a.y = y; a.y_bs = y_bs;

@@ -116,6 +116,24 @@ class PackedConv:
             wp[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
             self.wt_patch = wp.contiguous()
 
+        # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][Cout_pad][36] (k_local = c_local*9 + tap)
+        self.wt_dcn8 = None
+        if tap_major and kh == 3 and ci % 4 == 0 and self.Cout_pad % 64 == 0:
+            wd = torch.zeros(ci // 4, self.Cout_pad, 36, dtype=torch.float32, device=w.device)
+            wd[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
+            self.wt_dcn8 = wd.contiguous()
+
+    def dcn_tile(self, H, W):
+        """(tile code, utilisation) of the best 128-pixel 2-D tile for sgta_dcnv2_lds_f32."""
+        mt = 4 if self.Cout_pad % 128 == 0 else 2
+        best = None
+        for code, tw in ((0, 32), (1, 16), (2, 8)):
+            th = 128 // tw
+            util = (H * W) / float((-(-W // tw) * tw) * (-(-H // th) * th))
+            if best is None or util > best[1] + 1e-9:
+                best = (mt * 10 + code, util)
+        return best
+
     def patch_tile(self, W, tile=0, HW=None):
         """Tile id for sgta_conv3x3s1_f32, or 0 when that kernel does not cover (W, tile)."""
         if self.wt_patch is None:
@@ -180,6 +198,8 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
+USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)
+DCN_FORCE_MT = 0               # tools: force 64 (2) / 128 (4) couts per work-group
 USE_PATCH_KERNEL = True        # tools/tests flip this to time / check the generic implicit-GEMM path
 
 
@@ -201,6 +221,17 @@ def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     """Fused modulated deformable conv: ``om`` is the raw 27-channel offset/mask conv output."""
     x, om, out = as_view(x), as_view(om), as_view(out)
     assert om.C == 27 and x.C == pc.Cin and out.C == pc.Cout
+    if USE_DCN_LDS_KERNEL and pc.wt_dcn8 is not None and tile == 0:
+        code, _ = pc.dcn_tile(x.H, x.W)
+        if DCN_FORCE_MT:
+            code = DCN_FORCE_MT * 10 + code % 10
+        meta = None
+        if _lib.PROFILE is not None:
+            meta = _conv_meta(pc, out, 2, True)
+            meta["kernel"] = "dcn_patch_kernel<%d,%d>" % (code // 10, (32, 16, 8)[code % 10])
+        _lib.call("sgta_dcnv2_lds_f32", x.ptr, x.bs, om.ptr, om.bs, pc.wt_dcn8.data_ptr(), pc.bias.data_ptr(),
+                  out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act, code, _stream(), meta=meta)
+        return out
     _lib.call("sgta_dcnv2_fwd_f32", x.ptr, x.bs, om.ptr, om.bs, pc.wt.data_ptr(), pc.bias.data_ptr(),
               out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act, tile, _stream(),
               meta=_conv_meta(pc, out, tile, True) if _lib.PROFILE is not None else None)

@@ -42,6 +42,7 @@ def main():
     a = ap.parse_args()
     dev = "cuda:0"
     ops.USE_PATCH_KERNEL = not a.generic
+    ops.USE_DCN_LDS_KERNEL = not a.generic
     tiles = [int(t) for t in a.tiles.split(",")]
     for name, kind, ci, co, ks, st, H, W, N in SHAPES:
         if a.only and a.only not in name:
@@ -53,8 +54,14 @@ def main():
         out = torch.empty(N, co, Ho, Wo, device=dev)
         if kind == "dcn":
             pc = ops.PackedConv(w, None, tap_major=True)
-            om = torch.randn(N, 27, H, W, device=dev)
-            run = lambda t: ops.dcn_v2(x, om, pc, out, ops.ACT_RELU, tile=t)
+            om = torch.randn(N, 27, H, W, device=dev) * float(os.environ.get("OM_SCALE", "1.0"))
+            def run(t, x=x, om=om, pc=pc, out=out):
+                if a.generic:
+                    return ops.dcn_v2(x, om, pc, out, ops.ACT_RELU, tile=t)
+                ops.DCN_FORCE_MT = {1: 2, 2: 2, 3: 4}.get(t, 0)      # tile 2 -> 64 couts, 3 -> 128 couts
+                if ops.DCN_FORCE_MT == 4 and pc.Cout_pad % 128:
+                    raise ValueError
+                return ops.dcn_v2(x, om, pc, out, ops.ACT_RELU, tile=0)
         else:
             pc = ops.PackedConv(w, None, stride=st)
             run = lambda t: ops.conv2d(x, pc, out, ops.ACT_RELU, tile=t)
