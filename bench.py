@@ -128,15 +128,13 @@ def main():
     det = BatchedDetector(model)
     inp = make_inputs(B, H, W, seed=317 + rank * B)            # this rank's shard of the global batch
     dev_in = [inp[k].to(dev) for k in ARGS]
-    kp_all = torch.empty(world * B, 7, 3, dtype=torch.float32, device=dev)
+    from sgtapose_amd.distributed import gather_keypoints
+    state = {}
 
     def run_step():
         _, dets = det.process_device(*dev_in, static=True)
-        kp = det.keypoints(dets)
-        if dist is not None:
-            dist.all_gather_into_tensor(kp_all, kp)
-        else:
-            kp_all.copy_(kp)
+        # the path's only exchange step: all-gather of the [B,7,3] keypoints (RCCL when world > 1)
+        state["kp_all"] = gather_keypoints(det.keypoints(dets), world * B)
 
     def barrier():
         if dist is not None:

@@ -60,6 +60,16 @@ int sgta_conv3x3s1_f32(const float* x, long x_bs, const float* wt, const float* 
                        long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
                        int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
 
+/* The 16-output-channel convs on the full-resolution maps (MFMA 16x16x4, whole input window + weights in LDS):
+ *   mode 0: level0 = relu(bn(conv3x3(x [B,16,H,W])))                        (dla.py:246-247, :302-312); x2 = NULL
+ *           wt [144][16] with k = c*9 + ky*3 + kx (BN scale folded), bias [16]
+ *   mode 1: fused stems = relu(bn(conv7x7(x = image [B,3,H,W]))) + relu(bn(conv7x7(x2 = heat-map [B,1,H,W])))
+ *           (dla.py:259-270, :324-328); wt = two [196][16] matrices over the channel group {r,g,b,hm}
+ *           (k = ch*49 + ky*7 + kx; image matrix has zero rows for hm and vice versa), bias [32]. */
+int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt,
+                      const float* bias, float* y, long y_bs, int B, int H, int W, int mode,
+                      sgta_stream_t stream);
+
 /* Modulated deformable 3x3 conv v2 (stride 1, pad 1, dil 1, 1 deformable group) + folded BN + act,
  * gather fused into the GEMM (no column buffer).  Replaces the external lbin/DCNv2 ``dcn_v2_conv``
  * (import dla.py:21-25, constructed dla.py:545, called dla.py:548) and DeformConv's BN+ReLU

@@ -1,0 +1,127 @@
+// 16-output-channel convolutions on the full-resolution maps (gfx950, v_mfma_f32_16x16x4_f32):
+//   * level0: conv3x3(16->16)+BN+ReLU on [2B,16,H,W]                       (reference dla.py:246-247, :302-312)
+//   * the two live stems fused: relu(bn(conv7x7(img 3->16))) + relu(bn(conv7x7(hm 1->16)))
+//                                                                         (reference dla.py:259-270, :324-328)
+// These layers are balanced between HBM and the matrix cores (16 couts give ~18 MAC per byte), so a
+// 32-row MFMA tile would waste half the matrix time.  Here M = 16 couts exactly, one MFMA covers
+// 16 pixels x 4 k, and the k-slot index (lane>>4) selects one of 4 input channels, so the k-steps of a
+// channel group are simply the KS*KS taps.
+// A work-group owns an 8 x 32 pixel tile: it stages the (8+KS-1) x (32+KS-1) window of ALL input
+// channels (zero-filled outside the image, so the loop needs no border logic) and all weights in LDS
+// once, then runs barrier-free: per (tap, group) one A read, and per 16-pixel block one B read + MFMA.
+// The fused stem keeps two accumulators (image / heat-map conv) because each has its own BN+ReLU
+// before the sum; the heat-map plane rides in k-slot 3 of the single channel group {r,g,b,hm}.
+#include "common.h"
+
+struct C16Args {
+  const float* x;  long x_bs;      // main input [B, Cx, H, W]   (level0: 16 ch; stem: image, 3 ch)
+  const float* x2; long x2_bs;     // DUAL: heat-map input [B,1,H,W]
+  const float* wt;                 // [NG*4*KK][16] (k = ch*KK + tap); DUAL: second matrix follows
+  const float* bias;               // [16]; DUAL: [32] (image conv, heat-map conv)
+  float* y;        long y_bs;      // [B,16,H,W]
+  int B, H, W, tiles_x, tiles_y;
+};
+
+template <int KS, int NG, bool DUAL>
+__global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
+  constexpr int TH = 8, TW = 32, KK = KS * KS, P = KS / 2;
+  constexpr int WH = TH + KS - 1, WW = TW + KS - 1;
+  constexpr int WSZ0 = WH * WW, WSZ = WSZ0 + ((48 - WSZ0 % 32) % 32);     // plane stride == 16 (mod 32)
+  constexpr int NCH = NG * 4, NK = NCH * KK, NA = DUAL ? 2 : 1;
+  __shared__ float win[NCH * WSZ];
+  __shared__ float As[NA * NK * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x / tiles;
+  const int tr = blockIdx.x - b * tiles;
+  const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
+
+  // ---- stage window (zero outside the image) and weights -----------------------------------------
+  // all window loads of this thread are issued back to back (fixed trip count, registers), then stored
+  constexpr int P_PER = (NCH * WSZ0 + 255) / 256;
+  float pv[P_PER];
+#pragma unroll
+  for (int t = 0; t < P_PER; ++t) {
+    const int e = tid + t * 256;
+    const int ch = e / WSZ0, r = e - ch * WSZ0;
+    const int gy = ty0 - P + r / WW, gx = tx0 - P + r % WW;
+    const bool ok = e < NCH * WSZ0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int chc = ok ? ch : 0;                   // keep the unconditional load inside the tensor
+    const float* src = (DUAL && chc == 3) ? a.x2 + (long)b * a.x2_bs : a.x + (long)b * a.x_bs + (long)chc * HW;
+    const float v = src[ok ? gy * W + gx : 0];
+    pv[t] = ok ? v : 0.0f;
+  }
+  for (int e = tid; e < NA * NK * 16 / 4; e += 256)
+    reinterpret_cast<f32x4*>(As)[e] = reinterpret_cast<const f32x4*>(a.wt)[e];
+#pragma unroll
+  for (int t = 0; t < P_PER; ++t) {
+    const int e = tid + t * 256;
+    const int ch = e / WSZ0, r = e - ch * WSZ0;
+    if (e < NCH * WSZ0) win[ch * WSZ + r] = pv[t];
+  }
+  __syncthreads();
+
+  // wave w owns tile rows 2w, 2w+1; pixel block n: row 2w + n/2, columns (n&1)*16 .. +15
+  f32x4 acc[NA][4];
+#pragma unroll
+  for (int s = 0; s < NA; ++s)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[s][n] = f32x4{0, 0, 0, 0};
+
+#pragma unroll 1
+  for (int q = 0; q < NG; ++q) {
+    const float* wp = win + (4 * q + g) * WSZ + c16;
+    const float* ap = As + ((4 * q + g) * KK) * 16 + c16;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tap = ky * KS + kx;
+        float av[NA];
+#pragma unroll
+        for (int s = 0; s < NA; ++s) av[s] = ap[s * NK * 16 + tap * 16];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float bv = wp[(2 * wave + (n >> 1) + ky) * WW + (n & 1) * 16 + kx];
+#pragma unroll
+          for (int s = 0; s < NA; ++s)
+            acc[s][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[s][n], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- epilogue: C/D layout col = lane&15 (pixel), row = 4*(lane>>4) + r (cout) ---------------------
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int y = ty0 + 2 * wave + (n >> 1), x = tx0 + (n & 1) * 16 + c16;
+    if (y >= H || x >= W) continue;
+    float* yb = a.y + (long)b * a.y_bs + y * W + x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 4 * g + r;
+      float v = fmaxf(acc[0][n][r] + a.bias[co], 0.0f);
+      if (DUAL) v += fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
+      yb[(long)co * HW] = v;
+    }
+  }
+}
+
+extern "C" int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt,
+                                 const float* bias, float* y, long y_bs, int B, int H, int W, int mode,
+                                 hipStream_t st) {
+  if (!x || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
+  if ((long)16 * H * W > 0x7fffffffL) return SGTA_EBADARG;
+  C16Args a{x, x_bs, x2, x2_bs, wt, bias, y, y_bs, B, H, W, cdiv(W, 32), cdiv(H, 8)};
+  const int grid = B * a.tiles_x * a.tiles_y;
+  if (mode == 0)                                   // level0: 3x3, 16 -> 16, BN + ReLU
+    hipLaunchKernelGGL((conv_c16_kernel<3, 4, false>), dim3(grid), dim3(256), 0, st, a);
+  else if (mode == 1 && x2)                        // fused stems: 7x7 (3 -> 16) and (1 -> 16)
+    hipLaunchKernelGGL((conv_c16_kernel<7, 1, true>), dim3(grid), dim3(256), 0, st, a);
+  else
+    return SGTA_EBADARG;
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}

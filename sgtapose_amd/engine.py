@@ -39,6 +39,7 @@ class Engine:
         self.ks = list(model.kernel_list)
         self.scales = list(model.scale_list)
         self.num_classes = int(model.opt.num_classes)
+        self.use_c16 = True                  # 16-cout MFMA kernels for the stems / level0 (False: generic conv)
         self.compute_dead_levels = True      # levels 0/1 never reach the heads (dla.py:600-606); the
         #                                      reference still computes them, and so do we by default
         self.bufs = {}
@@ -53,6 +54,9 @@ class Engine:
             seq = getattr(b, stem)
             P[stem] = PackedConv(seq[0].weight, None, _bn_tuple(seq[1]), stride=1)
         P["level0"] = PackedConv(b.level0[0].weight, None, _bn_tuple(b.level0[1]), stride=1)
+        P["level0.c16"] = ops.PackedC16(b.level0[0].weight, _bn_tuple(b.level0[1]))
+        P["stem.c16"] = ops.PackedC16(b.pre_img_layer[0].weight, _bn_tuple(b.pre_img_layer[1]),
+                                       b.pre_hm_layer[0].weight, _bn_tuple(b.pre_hm_layer[1]))
         P["level1"] = PackedConv(b.level1[0].weight, None, _bn_tuple(b.level1[1]), stride=2)
 
         def pack_tree(node, name):
@@ -171,13 +175,19 @@ class Engine:
         N = 2 * B
         P = self.P
         s = self.buf("stem", (N, 16, H, W))
-        t = self.buf("stem_hm", (N, 16, H, W))
         for half, (img, hm) in enumerate(((pre_img, pre_hm), (x, repro_hm))):
             sl = slice(half * B, (half + 1) * B)
-            ops.conv2d(hm, P["pre_hm_layer"], View(t[sl]), ACT_RELU)
-            ops.conv2d(img, P["pre_img_layer"], View(s[sl]), ACT_RELU, res=View(t[sl]), res_mode=2)
+            if self.use_c16:                       # both 7x7 stems + BN + ReLU + sum in one kernel
+                ops.conv_c16(img, hm, P["stem.c16"], View(s[sl]))
+            else:
+                t = self.buf("stem_hm", (N, 16, H, W))
+                ops.conv2d(hm, P["pre_hm_layer"], View(t[sl]), ACT_RELU)
+                ops.conv2d(img, P["pre_img_layer"], View(s[sl]), ACT_RELU, res=View(t[sl]), res_mode=2)
         lv = [self.vbuf("l0", N, 16, H, W)]
-        ops.conv2d(View(s), P["level0"], lv[0], ACT_RELU)
+        if self.use_c16:
+            ops.conv_c16(View(s), None, P["level0.c16"], lv[0])
+        else:
+            ops.conv2d(View(s), P["level0"], lv[0], ACT_RELU)
         lv.append(self.vbuf("l1", N, 32, H // 2, W // 2))
         ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
         ch = self.model.base.channels

@@ -217,6 +217,50 @@ def _conv_meta(pc, out, tile, dcn, patch=False):
     return {"kernel": kern, "flops": pc.flops(M), "bytes": byts}
 
 
+class PackedC16:
+    """Weights of the 16-cout full-resolution layers (sgta_conv_c16_f32): level0 or the fused stems."""
+
+    def __init__(self, w_main, bn_main, w_hm=None, bn_hm=None):
+        w, b = fold_bn(w_main.detach().float(), None, bn_main)
+        co, ci, ks, _ = w.shape
+        assert co == 16
+        if w_hm is None:                        # level0: [144][16]
+            assert ci == 16 and ks == 3
+            self.mode, self.ks, self.cin = 0, 3, 16
+            self.wt = w.reshape(16, ci * ks * ks).t().contiguous()
+            self.bias = b.contiguous()
+        else:                                   # stems: channel group {r, g, b, hm}
+            assert ci == 3 and ks == 7
+            w2, b2 = fold_bn(w_hm.detach().float(), None, bn_hm)
+            kk = ks * ks
+            a_img = torch.zeros(4 * kk, 16, dtype=torch.float32, device=w.device)
+            a_hm = torch.zeros(4 * kk, 16, dtype=torch.float32, device=w.device)
+            a_img[:3 * kk] = w.reshape(16, 3 * kk).t()
+            a_hm[3 * kk:] = w2.reshape(16, kk).t()
+            self.mode, self.ks, self.cin = 1, 7, 4
+            self.wt = torch.cat([a_img, a_hm], 0).contiguous()
+            self.bias = torch.cat([b, b2]).contiguous()
+
+    def flops(self, M):
+        return 2.0 * M * 16 * self.cin * self.ks * self.ks
+
+
+def conv_c16(x, x2, pc, out):
+    x, out = as_view(x), as_view(out)
+    x2p, x2bs = None, 0
+    if x2 is not None:
+        x2 = as_view(x2)
+        x2p, x2bs = x2.ptr, x2.bs
+    meta = None
+    if _lib.PROFILE is not None:
+        M = out.B * out.H * out.W
+        meta = {"kernel": "conv_c16_kernel<%d>" % pc.ks, "flops": pc.flops(M),
+                "bytes": 4.0 * M * (pc.cin + 16)}
+    _lib.call("sgta_conv_c16_f32", x.ptr, x.bs, x2p, x2bs, pc.wt.data_ptr(), pc.bias.data_ptr(), out.ptr,
+              out.bs, x.B, x.H, x.W, pc.mode, _stream(), meta=meta)
+    return out
+
+
 def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     """Fused modulated deformable conv: ``om`` is the raw 27-channel offset/mask conv output."""
     x, om, out = as_view(x), as_view(om), as_view(out)

@@ -59,6 +59,28 @@ def test_conv2d_bn_relu_residual(ops, cin, cout, ks, stride, tile):
     assert torch.allclose(out.cpu(), torch.sigmoid(ref), atol=2e-5, rtol=1e-5)
 
 
+def test_conv_c16_level0_and_fused_stems(ops):
+    g = torch.Generator().manual_seed(21)
+    bn = lambda: (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1,
+                  torch.randn(16, generator=g) * 0.1, torch.rand(16, generator=g) + 0.5)
+    bnf = lambda y, p: F.batch_norm(y, p[2], p[3], p[0], p[1], False, 0.0, 1e-5)
+    for (B, H, W) in ((2, 16, 64), (3, 20, 45)):
+        x = torch.randn(B, 16, H, W, generator=g)
+        w = torch.randn(16, 16, 3, 3, generator=g) / 12
+        p0 = bn()
+        pc = ops.PackedC16(w.to(DEV), tuple(v.to(DEV) for v in p0))
+        out = torch.empty(B, 16, H, W, device=DEV)
+        ops.conv_c16(x.to(DEV), None, pc, out)
+        assert torch.allclose(out.cpu(), F.relu(bnf(F.conv2d(x, w, None, 1, 1), p0)), atol=2e-5, rtol=1e-5)
+        img, hm = torch.randn(B, 3, H, W, generator=g), torch.rand(B, 1, H, W, generator=g)
+        wi, wh = torch.randn(16, 3, 7, 7, generator=g) / 12, torch.randn(16, 1, 7, 7, generator=g) / 7
+        p1, p2 = bn(), bn()
+        ps = ops.PackedC16(wi.to(DEV), tuple(v.to(DEV) for v in p1), wh.to(DEV), tuple(v.to(DEV) for v in p2))
+        ops.conv_c16(img.to(DEV), hm.to(DEV), ps, out)
+        ref = F.relu(bnf(F.conv2d(img, wi, None, 1, 3), p1)) + F.relu(bnf(F.conv2d(hm, wh, None, 1, 3), p2))
+        assert torch.allclose(out.cpu(), ref, atol=2e-5, rtol=1e-5)
+
+
 def test_conv2d_channel_slice_views(ops):
     """input / output / residual as channel slices of wider (concat) buffers, batch > 1."""
     g = torch.Generator().manual_seed(5)

@@ -113,3 +113,29 @@ def test_fullnet_matches_reference(tag):
         ref = g["det_" + k]
         assert v.shape == ref.shape, k
         assert np.allclose(v, ref, atol=1e-5), k
+
+
+def test_dcnv2_torch_oracle_matches_plain_c_witness():
+    """oracle/dcnv2.py (torch) against oracle/dcnv2_ref.c (scalar C): two independent restatements of the
+    published lbin/DCNv2 algorithm (parity unpinned by the reference, see oracle/__init__.py)."""
+    import ctypes
+    import os
+    import subprocess
+    import torch.nn.functional as F
+    odir = os.path.dirname(os.path.abspath(oracle.__file__))
+    subprocess.check_call(["make", "-C", odir, "-s"])
+    lib = ctypes.CDLL(os.path.join(odir, "libdcnv2_ref.so"))
+    g = torch.Generator().manual_seed(4)
+    for (B, Ci, Co, H, W, s) in ((2, 8, 6, 7, 9, 1.5), (1, 16, 4, 5, 5, 6.0)):
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.2
+        b = torch.randn(Co, generator=g)
+        omw = torch.randn(27, Ci, 3, 3, generator=g) * (s / (Ci * 9) ** 0.5)
+        omb = torch.randn(27, generator=g) * 0.3
+        ref = oracle.dcn_v2_forward(x, w, b, omw, omb)
+        om = F.conv2d(x, omw, omb, padding=1).contiguous()
+        y = torch.empty(B, Co, H, W)
+        fp = lambda t_: ctypes.c_void_p(t_.data_ptr())
+        rc = lib.dcnv2_forward_ref(fp(x), fp(om), fp(w.contiguous()), fp(b), fp(y), B, Ci, H, W, Co)
+        assert rc == 0
+        assert torch.allclose(y, ref, atol=2e-5, rtol=1e-5), float((y - ref).abs().max())
