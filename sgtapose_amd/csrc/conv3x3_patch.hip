@@ -127,27 +127,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs a) {
     const bool more = kc + 1 < a.nchunks;
     if (more) issue(kc + 1);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < CK / 2; ++q) {
+    // software-pipelined k-steps (step = channel pair q x tap): operands of step s+1 are fetched from
+    // LDS before the MFMAs of step s issue, so LDS latency hides under 4*MT*NT*16 matrix cycles
+    constexpr int NSTEP = (CK / 2) * 9;
+    float av[2][MT], bv[2][NT];
+    auto fetch = [&](int step, int slot) {
+      const int q = step / 9, tap = step - q * 9;
+      const int toff = (tap / 3) * W + (tap % 3);
       const float* prow = &patch[st][2 * q + lh][0];
       const float* arow = &As[st][l31][(2 * q + lh) * 9];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int toff = (tap / 3) * W + (tap % 3);
-        float av[MT], bv[NT];
+      for (int i = 0; i < MT; ++i) av[slot][i] = arow[i * 32 * LDA + tap];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[i] = arow[i * 32 * LDA + tap];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const float v = prow[pxl[j] + toff];
-          bv[j] = tok[j][tap] ? v : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        const float v = prow[pxl[j] + toff];
+        bv[slot][j] = tok[j][tap] ? v : 0.0f;
       }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) fetch(step + 1, (step + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][i], bv[step & 1][j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (more) commit(st ^ 1);

@@ -154,45 +154,48 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
     const float* patch = lds + st * STAGE;
     const float* Asm = patch + P_PER * 256;
     const float* xc = xb + (long)kc * CK * HW;
+    // software-pipelined k-steps (step = tap x channel pair): the LDS gathers + blend of step s+1 are
+    // issued before the MFMAs of step s
+    constexpr int NSTEP = 9 * (CK / 2);
+    float av[2][MT], bv[2][NT];
+    auto fetch = [&](int step, int slot) {
+      const int tap = step / (CK / 2), q = step - tap * (CK / 2);
+      const int ch = 2 * q + lh;
+      const float* prow = patch + ch * PSZ;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+      for (int i = 0; i < MT; ++i) av[slot][i] = Asm[(i * 32 + l31) * LDA + ch * 9 + tap];
 #pragma unroll
-      for (int q = 0; q < CK / 2; ++q) {
-        const int ch = 2 * q + lh;
-        const float* prow = patch + ch * PSZ;
-        float av[MT], bv[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) av[i] = Asm[(i * 32 + l31) * LDA + ch * 9 + tap];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int lo0 = plo[tap][j] & 0xffffu, lo1 = plo[tap][j] >> 16;
-          float v00 = prow[lo0], v01 = prow[lo0 + 1], v10 = prow[lo1], v11 = prow[lo1 + 1];
-          if (any_out && ((outmask >> (tap * NT + j)) & 1u)) {   // rare: sample outside the staged window
-            const float* omp = a.om + (long)b * a.om_bs + py[j] * W + px[j];
-            const float sy = (float)(py[j] - 1 + tap / 3) + omp[(long)(2 * tap) * HW];
-            const float sx = (float)(px[j] - 1 + tap % 3) + omp[(long)(2 * tap + 1) * HW];
-            const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
-            const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
-            const int qx0 = min(max(x0, 0), W - 2);
-            const float* gp = xc + (long)ch * HW;
-            const F2g g0 = *reinterpret_cast<const F2g*>(gp + cy0 * W + qx0);
-            const F2g g1 = *reinterpret_cast<const F2g*>(gp + cy1 * W + qx0);
-            v00 = g0.a; v01 = g0.b; v10 = g1.a; v11 = g1.b;
-          }
-          float v = pw[tap][j][0] * v00;
-          v = fmaf(pw[tap][j][1], v01, v);
-          v = fmaf(pw[tap][j][2], v10, v);
-          v = fmaf(pw[tap][j][3], v11, v);
-          bv[j] = v;
+      for (int j = 0; j < NT; ++j) {
+        const int lo0 = plo[tap][j] & 0xffffu, lo1 = plo[tap][j] >> 16;
+        float v00 = prow[lo0], v01 = prow[lo0 + 1], v10 = prow[lo1], v11 = prow[lo1 + 1];
+        if (any_out && ((outmask >> (tap * NT + j)) & 1u)) {   // rare: sample outside the staged window
+          const float* omp = a.om + (long)b * a.om_bs + py[j] * W + px[j];
+          const float sy = (float)(py[j] - 1 + tap / 3) + omp[(long)(2 * tap) * HW];
+          const float sx = (float)(px[j] - 1 + tap % 3) + omp[(long)(2 * tap + 1) * HW];
+          const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+          const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+          const int qx0 = min(max(x0, 0), W - 2);
+          const float* gp = xc + (long)ch * HW;
+          const F2g g0 = *reinterpret_cast<const F2g*>(gp + cy0 * W + qx0);
+          const F2g g1 = *reinterpret_cast<const F2g*>(gp + cy1 * W + qx0);
+          v00 = g0.a; v01 = g0.b; v10 = g1.a; v11 = g1.b;
         }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        // keep the scheduler from hoisting every tap's LDS reads to the top of the chunk (spills)
-        if (q == CK / 2 - 1) __builtin_amdgcn_sched_barrier(0);
+        float v = pw[tap][j][0] * v00;
+        v = fmaf(pw[tap][j][1], v01, v);
+        v = fmaf(pw[tap][j][2], v10, v);
+        v = fmaf(pw[tap][j][3], v11, v);
+        bv[slot][j] = v;
       }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      if (step + 1 < NSTEP) fetch(step + 1, (step + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][i], bv[step & 1][j], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed (this wave's DMAs)
     __syncthreads();

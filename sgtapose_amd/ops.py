@@ -125,7 +125,7 @@ class PackedConv:
 
     def dcn_tile(self, H, W):
         """(tile code, utilisation) of the best 128-pixel 2-D tile for sgta_dcnv2_lds_f32."""
-        mt = 4 if self.Cout_pad % 128 == 0 else 2
+        mt = 2          # measured: 64 couts per work-group beats 128 (register pressure) on every DCN shape
         best = None
         for code, tw in ((0, 32), (1, 16), (2, 8)):
             th = 128 // tw
