@@ -27,9 +27,9 @@ struct PatchArgs {
   int tiles_per_img, n_ct, n_pt;
 };
 
-template <int MT, int NT, int CK, int PLT, int ACT, int RES>
+template <int MT, int NT, int CK, int PLMAX, int ACT, int RES>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs a) {
-  constexpr int BM = MT * 32, BN = 4 * NT * 32, KC = CK * 9, LDA = KC + 1, PLMAX = 256 * PLT;
+  constexpr int BM = MT * 32, BN = 4 * NT * 32, KC = CK * 9, LDA = KC + 1, PLT = (PLMAX + 255) / 256;
   constexpr int A_F4 = (BM * KC / 4 + 255) / 256;
   __shared__ float patch[2][CK][PLMAX];
   __shared__ float As[2][BM][LDA];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs a) {
 #pragma unroll
       for (int t = 0; t < PLT; ++t) {
         const int off = tid + t * 256;
-        if (PLT * 256 <= PLMAX || off < PLMAX) patch[st][c][off] = pok[t] ? preg[c][t] : 0.0f;
+        if (PLT * 256 <= PLMAX || off < PLMAX) patch[st][c][off] = pok[t] ? preg[c][t] : 0.0f;   // off < PL <= PLMAX when pok
       }
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
@@ -209,16 +209,23 @@ static int launch_patch(PatchArgs& a, int tile, hipStream_t st) {
   if (tile == 3 && a.Cout_pad % 128) tile = 2;
   if (tile == 2 && a.Cout_pad % 64) tile = 1;
   const int pl128 = 128 + 2 * W + 2, pl256 = 256 + 2 * W + 2;
+  // PLMAX (floats per channel in LDS) is picked as small as the map width allows: LDS, not registers,
+  // limits residency (4 work-groups per CU at <= 40 KB)
   switch (tile) {
     case 1:
-      if (pl256 <= 768) return go(conv3x3_patch_kernel<1, 2, CK, 3, ACT, RES>, 32, 256);
-      if (pl256 <= 1792) return go(conv3x3_patch_kernel<1, 2, CK, 7, ACT, RES>, 32, 256);
+      if (pl256 <= 448) return go(conv3x3_patch_kernel<1, 2, CK, 448, ACT, RES>, 32, 256);
+      if (pl256 <= 640) return go(conv3x3_patch_kernel<1, 2, CK, 640, ACT, RES>, 32, 256);
+      if (pl256 <= 768) return go(conv3x3_patch_kernel<1, 2, CK, 768, ACT, RES>, 32, 256);
+      if (pl256 <= 1792) return go(conv3x3_patch_kernel<1, 2, CK, 1792, ACT, RES>, 32, 256);
       break;
     case 2:
-      if (pl256 <= 768) return go(conv3x3_patch_kernel<2, 2, CK, 3, ACT, RES>, 64, 256);
+      if (pl256 <= 448) return go(conv3x3_patch_kernel<2, 2, CK, 448, ACT, RES>, 64, 256);
+      if (pl256 <= 640) return go(conv3x3_patch_kernel<2, 2, CK, 640, ACT, RES>, 64, 256);
+      if (pl256 <= 768) return go(conv3x3_patch_kernel<2, 2, CK, 768, ACT, RES>, 64, 256);
       break;
     case 3:
-      if (pl128 <= 512) return go(conv3x3_patch_kernel<4, 1, CK, 2, ACT, RES>, 128, 128);
+      if (pl128 <= 320) return go(conv3x3_patch_kernel<4, 1, CK, 320, ACT, RES>, 128, 128);
+      if (pl128 <= 512) return go(conv3x3_patch_kernel<4, 1, CK, 512, ACT, RES>, 128, 128);
       break;
   }
   return SGTA_EBADARG;                           // geometry not covered: caller uses sgta_conv2d_f32
