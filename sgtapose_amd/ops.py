@@ -116,6 +116,16 @@ class PackedConv:
             wp[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
             self.wt_patch = wp.contiguous()
 
+        # Winograd F(2x2,3x3): U = G g G^T, packed [Cin/8][16][Cout_pad][8]
+        self.u_wino = None
+        if kh == 3 and stride == 1 and self.pad == 1 and ci % 8 == 0 and not tap_major:
+            G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=w.device)
+            U = torch.einsum("xi,ocij,yj->ocxy", G, w.double(), G).float()          # [co, ci, 4, 4]
+            up = torch.zeros(ci // 8, 16, self.Cout_pad, 8, dtype=torch.float32, device=w.device)
+            # channel order inside a chunk: even channels then odd ones (one b128 per MFMA lane half)
+            order = torch.tensor([0, 2, 4, 6, 1, 3, 5, 7], device=w.device)
+            up[:, :, :co] = U.reshape(co, ci // 8, 8, 16)[:, :, order].permute(1, 3, 0, 2)
+            self.u_wino = up.contiguous()
         # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][Cout_pad][36] (k_local = c_local*9 + tap)
         self.wt_dcn8 = None
         if tap_major and kh == 3 and ci % 4 == 0 and self.Cout_pad % 64 == 0:
@@ -133,6 +143,18 @@ class PackedConv:
             if best is None or util > best[1] + 1e-9:
                 best = (mt * 10 + code, util)
         return best
+
+    def wino_tile(self, H, W):
+        """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape."""
+        mt = 2 if self.Cout_pad % 64 == 0 else 1
+        ty, tx = -(-H // 2), -(-W // 2)
+        best = None
+        for code, tc in ((0, 32), (1, 16), (2, 8)):
+            tr = 64 // tc
+            util = (ty * tx) / float((-(-ty // tr) * tr) * (-(-tx // tc) * tc))
+            if best is None or util > best[1] + 1e-9:
+                best = (mt * 10 + code, util)
+        return best[0]
 
     def patch_tile(self, W, tile=0, HW=None):
         """Tile id for sgta_conv3x3s1_f32, or 0 when that kernel does not cover (W, tile)."""
@@ -183,6 +205,16 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         res = as_view(res)
         assert res_mode in (1, 2) and res.C == pc.Cout and res.H == out.H and res.W == out.W
         rp, rbs = res.ptr, res.bs
+    if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
+        code = pc.wino_tile(x.H, x.W)
+        meta = None
+        if _lib.PROFILE is not None:
+            meta = _conv_meta(pc, out, 2, False)
+            meta["kernel"] = "conv3x3_wino_kernel<%d,%d>" % (code // 10, (32, 16, 8)[code % 10])
+        _lib.call("sgta_conv3x3_wino_f32", x.ptr, x.bs, pc.u_wino.data_ptr(), pc.bias.data_ptr(), rp, rbs,
+                  out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
+                  res_mode if res is not None else 0, code, _stream(), meta=meta)
+        return out
     pt = pc.patch_tile(x.W, tile, x.H * x.W) if USE_PATCH_KERNEL else 0
     if pt:
         _lib.call("sgta_conv3x3s1_f32", x.ptr, x.bs, pc.wt_patch.data_ptr(), pc.bias.data_ptr(), rp, rbs,
@@ -198,6 +230,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
+USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
 USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)
 DCN_FORCE_MT = 0               # tools: force 64 (2) / 128 (4) couts per work-group
 USE_PATCH_KERNEL = True        # tools/tests flip this to time / check the generic implicit-GEMM path
