@@ -38,6 +38,10 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 #endif
 }
 
+// padded, de-interleaved window row length: 2*WWP == 32/(32/TC) (mod 32) spreads the 32/TC tile rows of a
+// 32-lane group over disjoint bank ranges (TC = 8: WWP = 20, TC = 16: WWP = 40, TC = 32: WWP = 66)
+__host__ __device__ constexpr int wino_wwp(int TC) { return TC == 8 ? 20 : (TC == 16 ? 40 : 2 * TC + 2); }
+
 // One chunk of one position (xi, nu).  The position is wave-uniform but a RUN-TIME value: a 16-way
 // switch over compile-time positions made hipcc spill >500 registers; uniform offsets / signs in
 // scalar registers cost one add per LDS read instead.
@@ -46,7 +50,7 @@ template <int MT, int NT, int TC, int CK, int P_PER>
 __device__ __forceinline__ void wino_chunk(f32x16 (&acc)[MT][NT], const float* patch, const float* ul,
                                            const int (&tbase)[NT], int lh, int o11, int o12, int o21, int o22,
                                            float s12, float s21, float s22) {
-  constexpr int TR = 64 / TC, WH = 2 * TR + 2, WW = 2 * TC + 2, WSZ = WH * WW;
+  constexpr int TR = 64 / TC, WH = 2 * TR + 2, WSZ = WH * wino_wwp(TC);
   f32x4 a4[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) a4[i] = *reinterpret_cast<const f32x4*>(ul + i * 32 * CK);
@@ -71,18 +75,22 @@ __device__ __forceinline__ void wino_chunk(f32x16 (&acc)[MT][NT], const float* p
   }
 }
 
-template <int MT, int TC, int CK, int ACT, int RES>
-__global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
+template <int MT, int TC, int CK, int ACT, int RES, int EC, int NSTG>
+__device__ __forceinline__ void wino_body(const WinoArgs& a) {
   constexpr int NT = 2, BM = MT * 32, TR = 64 / TC;
-  constexpr int WH = 2 * TR + 2, WW = 2 * TC + 2, WSZ = WH * WW;
+  // Window rows are stored DE-INTERLEAVED ([even columns | odd columns], padded to WWP) so that the
+  // stride-2 column pattern of neighbouring tiles becomes unit-stride, and WWP is chosen so that the
+  // tile rows of a 32-lane group land on disjoint banks: B-operand reads are bank-conflict free.
+  constexpr int WH = 2 * TR + 2, WW = 2 * TC + 2, WWP = wino_wwp(TC), WSZ = WH * WWP;
   // U rows are 8 floats = the chunk's channels in the order [0,2,4,6 | 1,3,5,7] (host packing): lane half
   // lh fetches its four k-steps with ONE ds_read_b128, and the rows are staged by 16-byte LDS-DMA
   static_assert(CK == 8, "U row layout assumes 8 channels per chunk");
   constexpr int P_TOT = CK * WSZ, U_TOT4 = 16 * BM * CK / 4;             // U in float4 slots
   constexpr int P_PER = (P_TOT + 1023) / 1024, U_PER = (U_TOT4 + 1023) / 1024;
   constexpr int STAGE = P_PER * 1024 + U_PER * 4096;
-  constexpr int MLD = 65, M_TOT = 16 * 32 * MLD;
-  constexpr int LDS_F = (2 * STAGE > M_TOT ? 2 * STAGE : M_TOT);
+  constexpr int MLD = 65, M_TOT = 16 * EC * MLD;    // EC = output channels per epilogue pass (32 or 16)
+  // NSTG = LDS-DMA ring depth: 3 = two chunks in flight behind the one in use, 2 = one
+  constexpr int LDS_F = (NSTG * STAGE > M_TOT ? NSTG * STAGE : M_TOT);
   __shared__ __attribute__((aligned(16))) float lds[LDS_F + BM];
   float* const sbias = lds + LDS_F;
 
@@ -106,8 +114,10 @@ __global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
   for (int t = 0; t < P_PER; ++t) {
     const int e = tid + t * 1024;
     const int ch = e / WSZ, r = e - ch * WSZ;
-    const int gy = oy0 - 1 + r / WW, gx = ox0 - 1 + r % WW;
-    const bool ok = e < P_TOT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int sx = r % WWP;                        // slot in the de-interleaved row
+    const int col = sx < WW / 2 ? 2 * sx : 2 * (sx - WW / 2) + 1;
+    const int gy = oy0 - 1 + r / WWP, gx = ox0 - 1 + col;
+    const bool ok = e < P_TOT && sx < WW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     poff[t] = ok ? ch * HW + gy * W + gx : -1;
   }
 #pragma unroll
@@ -130,18 +140,20 @@ __global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
         glds16(uc + uoff[t], udst4 + t * 4096);
   };
   stage(0, 0);
+  if (NSTG == 3 && a.nchunks > 1) stage(1, 1);
 
   const int xi = wave >> 2, nu = wave & 3;          // this wave's Winograd position
   const int i1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), i2 = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
   const int j1 = nu == 0 ? 0 : (nu == 2 ? 2 : 1), j2 = nu == 0 ? 2 : (nu == 1 ? 2 : (nu == 2 ? 1 : 3));
   const float si2 = xi == 1 ? 1.0f : -1.0f, sj2 = nu == 1 ? 1.0f : -1.0f;     // first entries are +1
-  const int o11 = i1 * WW + j1, o12 = i1 * WW + j2, o21 = i2 * WW + j1, o22 = i2 * WW + j2;
+  const int c1 = (j1 & 1) * (WW / 2) + (j1 >> 1), c2 = (j2 & 1) * (WW / 2) + (j2 >> 1);
+  const int o11 = i1 * WWP + c1, o12 = i1 * WWP + c2, o21 = i2 * WWP + c1, o22 = i2 * WWP + c2;
   const float s12 = sj2, s21 = si2, s22 = si2 * sj2;
   int tbase[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int t = j * 32 + l31;
-    tbase[j] = (2 * (t / TC)) * WW + 2 * (t % TC);
+    tbase[j] = (2 * (t / TC)) * WWP + (t % TC);
   }
 
   f32x16 acc[MT][NT];
@@ -152,67 +164,79 @@ __global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // counted waits + raw barriers: __syncthreads() would drain every LDS-DMA in flight (vmcnt(0))
+  constexpr int G = P_PER + U_PER;                 // LDS-DMA instructions per wave and stage
+  if (NSTG == 3 && a.nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): sbias store
+  __builtin_amdgcn_s_barrier();
 
+  int st = 0;
   for (int kc = 0; kc < a.nchunks; ++kc) {
-    const int st = kc & 1;
-    if (kc + 1 < a.nchunks) stage(kc + 1, st ^ 1);
+    const bool issue = kc + (NSTG - 1) < a.nchunks;
+    if (issue) stage(kc + NSTG - 1, NSTG == 3 ? (st >= 1 ? st - 1 : 2) : (st ^ 1));   // (st + NSTG - 1) % NSTG
     const float* patch = lds + st * STAGE;
     wino_chunk<MT, NT, TC, CK, P_PER>(acc, patch, patch + P_PER * 1024 + (wave * BM + l31) * CK + lh * 4, tbase, lh,
                                       o11, o12, o21, o22, s12, s21, s22);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // chunk kc+1 must have landed; chunk kc+2 (just issued) may stay in flight
+    if (NSTG == 3 && issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    st = st == NSTG - 1 ? 0 : st + 1;
   }
 
   // ---- output transform through LDS: Mbuf[p][co_local 0..31][tile 0..63] ---------------------------
   float* Mbuf = lds;
+  constexpr int RPP = EC / 2;                      // accumulator registers per 32-row tile and pass
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+  for (int e = 0; e < BM / EC; ++e) {
+    const int i = (e * EC) / 32, r0 = ((e * EC) % 32) / 2;     // MFMA row tile and first register of the pass
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        Mbuf[(wave * 32 + col) * MLD + j * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < RPP; ++r) {
+        const int rr = r0 + r;
+        const int col = (rr & 3) + 8 * ((rr >> 2) - (r0 >> 2)) + 4 * lh;       // row inside this pass
+        Mbuf[(wave * EC + col) * MLD + j * 32 + l31] = acc[i][j][rr];
       }
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < EC * 64 / 1024; ++k) {
       const int item = tid + k * 1024;
       const int t = item & 63, col = item >> 6;
-      const int co = ct * BM + i * 32 + col;
+      const int co = ct * BM + e * EC + col;
       float m[4][4];
 #pragma unroll
-      for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = Mbuf[(p * 32 + col) * MLD + t];
-      float r0[4], r1[4];                          // A^T applied along nu
+      for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = Mbuf[(p * EC + col) * MLD + t];
+      float ra[4], rb[4];                          // A^T applied along nu
 #pragma unroll
       for (int x4 = 0; x4 < 4; ++x4) {
-        r0[x4] = (m[x4][0] + m[x4][1]) + m[x4][2];
-        r1[x4] = (m[x4][1] - m[x4][2]) - m[x4][3];
+        ra[x4] = (m[x4][0] + m[x4][1]) + m[x4][2];
+        rb[x4] = (m[x4][1] - m[x4][2]) - m[x4][3];
       }
-      float y00 = (r0[0] + r0[1]) + r0[2], y01 = (r1[0] + r1[1]) + r1[2];
-      float y10 = (r0[1] - r0[2]) - r0[3], y11 = (r1[1] - r1[2]) - r1[3];
+      float y00 = (ra[0] + ra[1]) + ra[2], y01 = (rb[0] + rb[1]) + rb[2];
+      float y10 = (ra[1] - ra[2]) - ra[3], y11 = (rb[1] - rb[2]) - rb[3];
       const int oy = oy0 + 2 * (t / TC), ox = ox0 + 2 * (t % TC);
       if (co < a.Cout && oy < H && ox < W) {
-        const float bsv = sbias[i * 32 + col];
+        const float bsv = sbias[e * EC + col];
         float* yp = a.y + (long)b * a.y_bs + (long)co * HW + oy * W + ox;
         const float* rp = RES ? a.res + (long)b * a.res_bs + (long)co * HW + oy * W + ox : nullptr;
         const bool x1 = ox + 1 < W, y1 = oy + 1 < H;
         float v[4] = {y00 + bsv, y01 + bsv, y10 + bsv, y11 + bsv};
-        float rr[4] = {0, 0, 0, 0};
+        float rr4[4] = {0, 0, 0, 0};
         if (RES) {
-          rr[0] = rp[0];
-          if (x1) rr[1] = rp[1];
-          if (y1) rr[2] = rp[W];
-          if (x1 && y1) rr[3] = rp[W + 1];
+          rr4[0] = rp[0];
+          if (x1) rr4[1] = rp[1];
+          if (y1) rr4[2] = rp[W];
+          if (x1 && y1) rr4[3] = rp[W + 1];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (RES == 1) v[e] += rr[e];
-          if (ACT == 1) v[e] = fmaxf(v[e], 0.0f);
-          if (ACT == 2) v[e] = sigmoidf_(v[e]);
-          if (RES == 2) v[e] += rr[e];
+        for (int q = 0; q < 4; ++q) {
+          if (RES == 1) v[q] += rr4[q];
+          if (ACT == 1) v[q] = fmaxf(v[q], 0.0f);
+          if (ACT == 2) v[q] = sigmoidf_(v[q]);
+          if (RES == 2) v[q] += rr4[q];
         }
         yp[0] = v[0];
         if (x1) yp[1] = v[1];
@@ -220,8 +244,22 @@ __global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
         if (x1 && y1) yp[W + 1] = v[3];
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
   }
+}
+
+// 64 output channels per work-group: one 16-wave work-group per CU (<= 128 registers, 3-deep LDS-DMA ring)
+template <int TC, int CK, int ACT, int RES>
+__global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
+  wino_body<2, TC, CK, ACT, RES, 32, 3>(a);
+}
+
+// 32 output channels per work-group, sized (<= 64 registers, <= 80 KB LDS) so that TWO 16-wave work-groups
+// share a CU: one's prologue / output transform overlaps the other's MFMA loop
+template <int TC, int CK, int ACT, int RES>
+__global__ __launch_bounds__(1024, 8) void conv3x3_wino32_kernel(WinoArgs a) {
+  wino_body<1, TC, CK, ACT, RES, 16, 2>(a);
 }
 
 template <int ACT, int RES>
@@ -241,14 +279,16 @@ static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
   // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2} = 2x32 / 4x16 / 8x8 tile blocks
   const int mt = tile / 10, tc = tile % 10;
   if (mt == 2 && a.Cout_pad % 64 == 0) {
-    if (tc == 0) return go(conv3x3_wino_kernel<2, 32, CK, ACT, RES>, 64, 32);
-    if (tc == 1) return go(conv3x3_wino_kernel<2, 16, CK, ACT, RES>, 64, 16);
-    if (tc == 2) return go(conv3x3_wino_kernel<2, 8, CK, ACT, RES>, 64, 8);
+    if (tc == 0) return go(conv3x3_wino_kernel<32, CK, ACT, RES>, 64, 32);
+    if (tc == 1) return go(conv3x3_wino_kernel<16, CK, ACT, RES>, 64, 16);
+    if (tc == 2) return go(conv3x3_wino_kernel<8, CK, ACT, RES>, 64, 8);
   }
   if (mt == 1) {
-    if (tc == 0) return go(conv3x3_wino_kernel<1, 32, CK, ACT, RES>, 32, 32);
-    if (tc == 1) return go(conv3x3_wino_kernel<1, 16, CK, ACT, RES>, 32, 16);
-    if (tc == 2) return go(conv3x3_wino_kernel<1, 8, CK, ACT, RES>, 32, 8);
+    // 32 couts: <= 64 registers and <= 80 KB of LDS, so TWO 16-wave work-groups share a CU and one's
+    // prologue / output transform overlaps the other's MFMA loop
+    if (tc == 0) return go(conv3x3_wino32_kernel<32, CK, ACT, RES>, 32, 32);
+    if (tc == 1) return go(conv3x3_wino32_kernel<16, CK, ACT, RES>, 32, 16);
+    if (tc == 2) return go(conv3x3_wino32_kernel<8, CK, ACT, RES>, 32, 8);
   }
   return SGTA_EBADARG;
 }

@@ -146,7 +146,7 @@ class PackedConv:
 
     def wino_tile(self, H, W):
         """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape."""
-        mt = 2 if self.Cout_pad % 64 == 0 else 1
+        mt = 2 if (self.Cout_pad % 64 == 0 and not WINO_FORCE_MT1) else 1
         ty, tx = -(-H // 2), -(-W // 2)
         best = None
         for code, tc in ((0, 32), (1, 16), (2, 8)):
@@ -230,6 +230,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
+WINO_FORCE_MT1 = False         # tools: 32-cout Winograd tiles (two work-groups per CU) everywhere
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
 USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)
 DCN_FORCE_MT = 0               # tools: force 64 (2) / 128 (4) couts per work-group
