@@ -211,6 +211,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, False)
             meta["kernel"] = "conv3x3_wino_kernel<%d,%d>" % (code // 10, (32, 16, 8)[code % 10])
+            meta["exec_flops"] = meta["flops"] * 16.0 / 36.0      # F(2x2,3x3): 16 of 36 multiplies
         _lib.call("sgta_conv3x3_wino_f32", x.ptr, x.bs, pc.u_wino.data_ptr(), pc.bias.data_ptr(), rp, rbs,
                   out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
                   res_mode if res is not None else 0, code, _stream(), meta=meta)
@@ -248,7 +249,7 @@ def _conv_meta(pc, out, tile, dcn, patch=False):
         kern = "conv3x3_patch_kernel<%s>" % mt_nt
     hw_in = M * pc.stride * pc.stride
     byts = 4.0 * (pc.Cin * hw_in + pc.Cout * M + (27 * M if dcn else 0)) + 4.0 * pc.Cout * pc.Cin * pc.ks ** 2
-    return {"kernel": kern, "flops": pc.flops(M), "bytes": byts}
+    return {"kernel": kern, "flops": pc.flops(M), "bytes": byts, "exec_flops": pc.flops(M)}
 
 
 class PackedC16:
@@ -288,8 +289,9 @@ def conv_c16(x, x2, pc, out):
     meta = None
     if _lib.PROFILE is not None:
         M = out.B * out.H * out.W
-        meta = {"kernel": "conv_c16_kernel<%d>" % pc.ks, "flops": pc.flops(M),
-                "bytes": 4.0 * M * (pc.cin + 16)}
+        meta = {"kernel": "conv_c16_kernel<%d>" % pc.ks, "flops": pc.flops(M), "bytes": 4.0 * M * (pc.cin + 16),
+                # fused stems issue two MFMAs per tap over the 4-slot group {r,g,b,hm} (zero-padded slots)
+                "exec_flops": pc.flops(M) * (2.0 if pc.mode == 1 else 1.0)}
     _lib.call("sgta_conv_c16_f32", x.ptr, x.bs, x2p, x2bs, pc.wt.data_ptr(), pc.bias.data_ptr(), out.ptr,
               out.bs, x.B, x.H, x.W, pc.mode, _stream(), meta=meta)
     return out

@@ -59,6 +59,32 @@ def test_conv2d_bn_relu_residual(ops, cin, cout, ks, stride, tile):
     assert torch.allclose(out.cpu(), torch.sigmoid(ref), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 24, 40), (128, 27, 15, 20), (16, 96, 17, 23), (64, 768, 8, 12), (512, 512, 15, 20)])
+def test_conv3x3_three_implementations_agree(ops, cin, cout, H, W):
+    """Winograd F(2x2,3x3), the LDS-range direct kernel and the generic implicit GEMM against torch,
+    incl. odd map sizes (partial 2x2 tiles), residual + ReLU, and a non-multiple-of-32 Cout."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref = F.relu(F.conv2d(x, w, bias, padding=1) + res)
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV))
+    assert pc.u_wino is not None and pc.wt_patch is not None
+    out = torch.empty(ref.shape, device=DEV)
+    flags = (ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL)
+    try:
+        for wino, patch in ((True, True), (False, True), (False, False)):
+            ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = wino, patch
+            out.zero_()
+            ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU, res=res.to(DEV), res_mode=1)
+            err = float((out.cpu() - ref).abs().max())
+            assert err < (1e-4 if wino else 3e-5), (wino, patch, err)
+    finally:
+        ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = flags
+
+
 def test_conv_c16_level0_and_fused_stems(ops):
     g = torch.Generator().manual_seed(21)
     bn = lambda: (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1,
