@@ -74,8 +74,8 @@ int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float
  *   mode 0: level0 = relu(bn(conv3x3(x [B,16,H,W])))                        (dla.py:246-247, :302-312); x2 = NULL
  *           wt [144][16] with k = c*9 + ky*3 + kx (BN scale folded), bias [16]
  *   mode 1: fused stems = relu(bn(conv7x7(x = image [B,3,H,W]))) + relu(bn(conv7x7(x2 = heat-map [B,1,H,W])))
- *           (dla.py:259-270, :324-328); wt = two [196][16] matrices over the channel group {r,g,b,hm}
- *           (k = ch*49 + ky*7 + kx; image matrix has zero rows for hm and vice versa), bias [32]. */
+ *           (dla.py:259-270, :324-328); wt = [148][16] image matrix (k = ch*49 + ky*7 + kx, row 147 zero)
+ *           followed by [52][16] heat-map matrix (k = ky*7 + kx, rows 49..51 zero), bias [32]. */
 int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt,
                       const float* bias, float* y, long y_bs, int B, int H, int W, int mode,
                       sgta_stream_t stream);

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
   constexpr int WSZ0 = WH * WW, WSZ = WSZ0 + ((48 - WSZ0 % 32) % 32);     // plane stride == 16 (mod 32)
   constexpr int NCH = NG * 4, NK = NCH * KK, NA = DUAL ? 2 : 1;
   __shared__ float win[NCH * WSZ];
-  __shared__ float As[NA * NK * 16];
+  __shared__ __attribute__((aligned(16))) float As[NA * NK * 16];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g = lane >> 4;
@@ -54,8 +54,18 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
     const float v = src[ok ? gy * W + gx : 0];
     pv[t] = ok ? v : 0.0f;
   }
-  for (int e = tid; e < NA * NK * 16 / 4; e += 256)
-    reinterpret_cast<f32x4*>(As)[e] = reinterpret_cast<const f32x4*>(a.wt)[e];
+  constexpr int A_PER = (NA * NK * 16 / 4 + 255) / 256;   // fixed trip count: all weight loads in flight together
+  f32x4 wv[A_PER];
+#pragma unroll
+  for (int t = 0; t < A_PER; ++t) {
+    const int e = tid + t * 256;
+    wv[t] = reinterpret_cast<const f32x4*>(a.wt)[e < NA * NK * 16 / 4 ? e : 0];
+  }
+#pragma unroll
+  for (int t = 0; t < A_PER; ++t) {
+    const int e = tid + t * 256;
+    if (e < NA * NK * 16 / 4) reinterpret_cast<f32x4*>(As)[e] = wv[t];
+  }
 #pragma unroll
   for (int t = 0; t < P_PER; ++t) {
     const int e = tid + t * 256;
@@ -109,6 +119,108 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
   }
 }
 
+// ---- fused stems, flattened-k form ---------------------------------------------------------------------
+// relu(bn(conv7x7(img))) + relu(bn(conv7x7(hm))): the image conv walks k = ch*49 + tap (147 -> 37 k-steps
+// of 4), the heat-map conv k = tap (49 -> 13 k-steps); MFMA k-slot g of step s takes k = 4s + g, so each
+// lane keeps the window offset of ITS k in a register (37 + 13 registers) -- no zero-padded channel
+// slots: 50 MFMAs per 16 pixels instead of 98.
+__global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
+  constexpr int KS = 7, TH = 8, TW = 32, KK = 49, P = 3;
+  constexpr int WH = TH + KS - 1, WW = TW + KS - 1;
+  constexpr int WSZ0 = WH * WW, WSZ = WSZ0 + ((48 - WSZ0 % 32) % 32);
+  constexpr int NCH = 4, SI = 37, SH = 13, NKI = SI * 4, NKH = SH * 4;     // 148 / 52 padded k
+  __shared__ float win[NCH * WSZ];
+  __shared__ __attribute__((aligned(16))) float As[(NKI + NKH) * 16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, g = lane >> 4;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int b = blockIdx.x / tiles;
+  const int tr = blockIdx.x - b * tiles;
+  const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
+
+  constexpr int P_PER = (NCH * WSZ0 + 255) / 256;
+  float pv[P_PER];
+#pragma unroll
+  for (int t = 0; t < P_PER; ++t) {
+    const int e = tid + t * 256;
+    const int ch = e / WSZ0, r = e - ch * WSZ0;
+    const int gy = ty0 - P + r / WW, gx = tx0 - P + r % WW;
+    const bool ok = e < NCH * WSZ0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const int chc = ok ? ch : 0;
+    const float* src = chc == 3 ? a.x2 + (long)b * a.x2_bs : a.x + (long)b * a.x_bs + (long)chc * HW;
+    const float v = src[ok ? gy * W + gx : 0];
+    pv[t] = ok ? v : 0.0f;
+  }
+  constexpr int A_PER = ((NKI + NKH) * 16 / 4 + 255) / 256;
+  f32x4 wv[A_PER];
+#pragma unroll
+  for (int t = 0; t < A_PER; ++t) {
+    const int e = tid + t * 256;
+    wv[t] = reinterpret_cast<const f32x4*>(a.wt)[e < (NKI + NKH) * 4 ? e : 0];
+  }
+#pragma unroll
+  for (int t = 0; t < P_PER; ++t) {
+    const int e = tid + t * 256;
+    const int ch = e / WSZ0, r = e - ch * WSZ0;
+    if (e < NCH * WSZ0) win[ch * WSZ + r] = pv[t];
+  }
+#pragma unroll
+  for (int t = 0; t < A_PER; ++t) {
+    const int e = tid + t * 256;
+    if (e < (NKI + NKH) * 4) reinterpret_cast<f32x4*>(As)[e] = wv[t];
+  }
+
+  // this lane's window offset for every k-step (k = 4s + g)
+  int offi[SI], offh[SH];
+#pragma unroll
+  for (int s2 = 0; s2 < SI; ++s2) {
+    const int k = 4 * s2 + g, ch = k / KK, tap = k - ch * KK;
+    offi[s2] = k < 3 * KK ? ch * WSZ + (tap / KS) * WW + tap % KS : 0;      // k = 147: zero weight row
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < SH; ++s2) {
+    const int k = 4 * s2 + g;
+    offh[s2] = k < KK ? 3 * WSZ + (k / KS) * WW + k % KS : 3 * WSZ;
+  }
+  int pix[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) pix[n] = (2 * wave + (n >> 1)) * WW + (n & 1) * 16 + c16;
+  __syncthreads();
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[s2][n] = f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int s2 = 0; s2 < SI; ++s2) {
+    const float av = As[(4 * s2 + g) * 16 + c16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, win[offi[s2] + pix[n]], acc[0][n], 0, 0, 0);
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < SH; ++s2) {
+    const float av = As[(NKI + 4 * s2 + g) * 16 + c16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, win[offh[s2] + pix[n]], acc[1][n], 0, 0, 0);
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int y = ty0 + 2 * wave + (n >> 1), x = tx0 + (n & 1) * 16 + c16;
+    if (y >= H || x >= W) continue;
+    float* yb = a.y + (long)b * a.y_bs + y * W + x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 4 * g + r;
+      yb[(long)co * HW] = fmaxf(acc[0][n][r] + a.bias[co], 0.0f) + fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
+    }
+  }
+}
+
 extern "C" int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt,
                                  const float* bias, float* y, long y_bs, int B, int H, int W, int mode,
                                  hipStream_t st) {
@@ -119,7 +231,7 @@ extern "C" int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, lon
   if (mode == 0)                                   // level0: 3x3, 16 -> 16, BN + ReLU
     hipLaunchKernelGGL((conv_c16_kernel<3, 4, false>), dim3(grid), dim3(256), 0, st, a);
   else if (mode == 1 && x2)                        // fused stems: 7x7 (3 -> 16) and (1 -> 16)
-    hipLaunchKernelGGL((conv_c16_kernel<7, 1, true>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(stem_c16_kernel, dim3(grid), dim3(256), 0, st, a);
   else
     return SGTA_EBADARG;
   SGTA_LAUNCH_CHECK();

@@ -268,10 +268,11 @@ class PackedC16:
             assert ci == 3 and ks == 7
             w2, b2 = fold_bn(w_hm.detach().float(), None, bn_hm)
             kk = ks * ks
-            a_img = torch.zeros(4 * kk, 16, dtype=torch.float32, device=w.device)
-            a_hm = torch.zeros(4 * kk, 16, dtype=torch.float32, device=w.device)
+            # flattened k: image conv k = ch*49 + tap (147 -> 148 rows), heat-map conv k = tap (49 -> 52 rows)
+            a_img = torch.zeros(148, 16, dtype=torch.float32, device=w.device)
+            a_hm = torch.zeros(52, 16, dtype=torch.float32, device=w.device)
             a_img[:3 * kk] = w.reshape(16, 3 * kk).t()
-            a_hm[3 * kk:] = w2.reshape(16, kk).t()
+            a_hm[:kk] = w2.reshape(16, kk).t()
             self.mode, self.ks, self.cin = 1, 7, 4
             self.wt = torch.cat([a_img, a_hm], 0).contiguous()
             self.bias = torch.cat([b, b2]).contiguous()
@@ -290,8 +291,7 @@ def conv_c16(x, x2, pc, out):
     if _lib.PROFILE is not None:
         M = out.B * out.H * out.W
         meta = {"kernel": "conv_c16_kernel<%d>" % pc.ks, "flops": pc.flops(M), "bytes": 4.0 * M * (pc.cin + 16),
-                # fused stems issue two MFMAs per tap over the 4-slot group {r,g,b,hm} (zero-padded slots)
-                "exec_flops": pc.flops(M) * (2.0 if pc.mode == 1 else 1.0)}
+                "exec_flops": pc.flops(M) * (200.0 / 196.0 if pc.mode == 1 else 1.0)}     # 148 + 52 padded k
     _lib.call("sgta_conv_c16_f32", x.ptr, x.bs, x2p, x2bs, pc.wt.data_ptr(), pc.bias.data_ptr(), out.ptr,
               out.bs, x.B, x.H, x.W, pc.mode, _stream(), meta=meta)
     return out
