@@ -65,7 +65,7 @@ int sgta_conv3x3s1_f32(const float* x, long x_bs, const float* wt, const float* 
  * u : host-transformed weights G g G^T, packed [Cin/8][16][Cout_pad][8]: element (c/8, xi*4+nu, co, s) with
  *     the 8 channels of a chunk stored in the order s -> c%8 = 0,2,4,6,1,3,5,7.
  * tile = 10*MT + t: MT in {1,2} = 32 / 64 output channels per work-group (MT=2 needs Cout_pad % 64 == 0),
- * t in {0,1,2} = 2x32 / 4x16 / 8x8 blocks of 2x2-pixel tiles. */
+ * t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2-pixel tiles. */
 int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float* bias, const float* res,
                           long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
                           int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);

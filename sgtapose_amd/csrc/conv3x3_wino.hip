@@ -39,8 +39,8 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 }
 
 // padded, de-interleaved window row length: 2*WWP == 32/(32/TC) (mod 32) spreads the 32/TC tile rows of a
-// 32-lane group over disjoint bank ranges (TC = 8: WWP = 20, TC = 16: WWP = 40, TC = 32: WWP = 66)
-__host__ __device__ constexpr int wino_wwp(int TC) { return TC == 8 ? 20 : (TC == 16 ? 40 : 2 * TC + 2); }
+// 32-lane group over disjoint bank ranges (TC = 4: WWP = 18, TC = 8: 20, TC = 16: 40, TC = 32: 66)
+__host__ __device__ constexpr int wino_wwp(int TC) { return TC == 4 ? 18 : (TC == 8 ? 20 : (TC == 16 ? 40 : 2 * TC + 2)); }
 
 // One chunk of one position (xi, nu).  The position is wave-uniform but a RUN-TIME value: a 16-way
 // switch over compile-time positions made hipcc spill >500 registers; uniform offsets / signs in
@@ -276,12 +276,13 @@ static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   };
-  // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2} = 2x32 / 4x16 / 8x8 tile blocks
+  // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 tile blocks
   const int mt = tile / 10, tc = tile % 10;
   if (mt == 2 && a.Cout_pad % 64 == 0) {
     if (tc == 0) return go(conv3x3_wino_kernel<32, CK, ACT, RES>, 64, 32);
     if (tc == 1) return go(conv3x3_wino_kernel<16, CK, ACT, RES>, 64, 16);
     if (tc == 2) return go(conv3x3_wino_kernel<8, CK, ACT, RES>, 64, 8);
+    if (tc == 3) return go(conv3x3_wino_kernel<4, CK, ACT, RES>, 64, 4);
   }
   if (mt == 1) {
     // 32 couts: <= 64 registers and <= 80 KB of LDS, so TWO 16-wave work-groups share a CU and one's
@@ -289,6 +290,7 @@ static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
     if (tc == 0) return go(conv3x3_wino32_kernel<32, CK, ACT, RES>, 32, 32);
     if (tc == 1) return go(conv3x3_wino32_kernel<16, CK, ACT, RES>, 32, 16);
     if (tc == 2) return go(conv3x3_wino32_kernel<8, CK, ACT, RES>, 32, 8);
+    if (tc == 3) return go(conv3x3_wino32_kernel<4, CK, ACT, RES>, 32, 4);
   }
   return SGTA_EBADARG;
 }

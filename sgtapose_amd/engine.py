@@ -39,6 +39,7 @@ class Engine:
         self.ks = list(model.kernel_list)
         self.scales = list(model.scale_list)
         self.num_classes = int(model.opt.num_classes)
+        self.use_side_stream = True          # overlap the (dead-end) level-0/1 attention with the neck / heads
         self.use_c16 = True                  # 16-cout MFMA kernels for the stems / level0 (False: generic conv)
         self.compute_dead_levels = True      # levels 0/1 never reach the heads (dla.py:600-606); the
         #                                      reference still computes them, and so do we by default
@@ -198,12 +199,11 @@ class Engine:
         return lv
 
     # ------------------------------------------------------------------------------------------
-    def temporal(self, lv, pre_cls, cur_cls, B):
-        """In-place temporal stage on the current-frame halves of ``lv``; returns (fid0_pre, fid0_cur)."""
+    def temporal(self, lv, idx, B, levels):
+        """In-place temporal stage on the current-frame halves of ``lv`` for the given pyramid levels;
+        ``idx`` = prior arg-max coordinates.  Returns the level-0 window ids (or None)."""
         K = self.num_classes
-        idx = ops.prior_argmax(pre_cls, cur_cls, self.buf("idx", (2, B, K, 2)))
         fid0 = None
-        levels = range(6) if self.compute_dead_levels else (2, 3, 4, 5)
         for i in levels:
             feats = lv[i]
             C, H, W = feats.C, feats.H, feats.W
@@ -305,8 +305,31 @@ class Engine:
             raise ValueError("pre_hm_cls must be [B,%d,H/4,W/4]" % self.num_classes)
         with torch.no_grad():
             lv = self.backbone(x, pre_img, pre_hm, repro_hm)
-            self.last_fid0 = self.temporal(lv, pre_hm_cls, repro_hm_cls, B)
+            idx = ops.prior_argmax(pre_hm_cls, repro_hm_cls, self.buf("idx", (2, B, self.num_classes, 2)))
+            # Levels 0 and 1 never reach the heads (dla_up starts at level 2, dla.py:600-606): their
+            # attention (the largest token counts, latency-bound kernels) runs on a side stream beside the
+            # MFMA-bound neck / heads; levels 2-5 feed the neck and stay on the main stream.
+            main = torch.cuda.current_stream()
+            side = None
+            self.last_fid0 = None
+            if self.compute_dead_levels:
+                if self.use_side_stream and _lib.PROFILE is None:
+                    side = self._side_stream()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self.last_fid0 = self.temporal(lv, idx, B, (0, 1))
+                else:
+                    self.last_fid0 = self.temporal(lv, idx, B, (0, 1))
+            self.temporal(lv, idx, B, (2, 3, 4, 5))
             cur = [View(v.base[B:]) for v in lv]
             feat = self.neck(cur)
             self.last_feat = feat
-            return self.heads(feat, hm_act, static)
+            out = self.heads(feat, hm_act, static)
+            if side is not None:
+                main.wait_stream(side)             # the step is complete only when the side work is
+            return out
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side

@@ -149,7 +149,7 @@ class PackedConv:
         mt = 2 if (self.Cout_pad % 64 == 0 and not WINO_FORCE_MT1) else 1
         ty, tx = -(-H // 2), -(-W // 2)
         best = None
-        for code, tc in ((0, 32), (1, 16), (2, 8)):
+        for code, tc in ((0, 32), (1, 16), (2, 8), (3, 4)):
             tr = 64 // tc
             util = (ty * tx) / float((-(-ty // tr) * tr) * (-(-tx // tc) * tc))
             if best is None or util > best[1] + 1e-9:
@@ -210,7 +210,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         meta = None
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, False)
-            meta["kernel"] = "conv3x3_wino_kernel<%d,%d>" % (code // 10, (32, 16, 8)[code % 10])
+            meta["kernel"] = "conv3x3_wino_kernel<%d,%d>" % (code // 10, (32, 16, 8, 4)[code % 10])
             meta["exec_flops"] = meta["flops"] * 16.0 / 36.0      # F(2x2,3x3): 16 of 36 multiplies
         _lib.call("sgta_conv3x3_wino_f32", x.ptr, x.bs, pc.u_wino.data_ptr(), pc.bias.data_ptr(), rp, rbs,
                   out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,

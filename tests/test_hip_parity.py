@@ -307,6 +307,26 @@ def test_fullnet_matches_reference(model, tag):
         assert err < 1e-3, (k, err)
 
 
+def test_side_stream_overlap_is_bit_identical(model):
+    from sgtapose_amd.synthetic import make_inputs
+    inp = make_inputs(2, 128, 160, seed=9)
+    dev = [inp[k].to(DEV) for k in ARGS]
+    eng = model.engine()
+    a = {k: v.clone() for k, v in model(*dev)[-1].items()}
+    fid_a = eng.last_fid0.clone()
+    l0_a = eng.bufs[("l0", (4, 16, 128, 160), torch.float32)].clone()
+    eng.use_side_stream = False
+    try:
+        b = model(*dev)[-1]
+        torch.cuda.synchronize()
+        assert torch.equal(fid_a, eng.last_fid0)
+        assert torch.equal(l0_a, eng.bufs[("l0", (4, 16, 128, 160), torch.float32)])   # level-0 substitution result
+    finally:
+        eng.use_side_stream = True
+    for k in a:
+        assert torch.equal(a[k], b[k])
+
+
 def test_skipping_dead_levels_changes_nothing(model):
     from sgtapose_amd.synthetic import make_inputs
     inp = make_inputs(2, 128, 128, seed=317)
