@@ -363,3 +363,16 @@ def test_process_contract_and_keypoints_on_peaked_maps(model):
     assert torch.equal(got["xs"].cpu(), ref["xs"]) and torch.equal(got["ys"].cpu(), ref["ys"])
     assert torch.equal(got["cts_wreg"].cpu(), ref["cts_wreg"])
     assert int((got["scores"] > 0).sum()) == 21
+
+
+def test_large_nonsquare_input_matches_oracle(model):
+    """BASELINE configs[3] geometry (720p padded to 736x1280, feature maps 184x320): exercises the kernels'
+    fallbacks for wide maps against the CPU oracle (no reference vector exists at this size)."""
+    from sgtapose_amd.synthetic import make_inputs
+    inp = make_inputs(1, 736, 1280, seed=41)
+    out = model(*[inp[k].to(DEV) for k in ARGS])[-1]
+    ref = oracle.plan_a_window_forward(golden_state_dict(), *[inp[k] for k in ARGS])
+    for k in ("hm", "reg", "tracking"):
+        assert out[k].shape == ref[k].shape
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        assert err < 1e-3, (k, err)
