@@ -70,6 +70,15 @@ int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float
                           long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
                           int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
 
+/* 1x1 conv (+ bias, residual, activation) as a GEMM over the flattened pixels, both operands staged by
+ * 16-byte LDS-DMA (Root / project convs, dla.py:157-175, :211-216; second conv of the heads,
+ * base_model.py:122-123).  wt : packed [Cin_pad/16][Cout_pad][20], element (c/16, co, c%16) = W[co][c]*bn_scale[co]
+ * (4 pad floats per row, zero beyond Cin / Cout).  Requires (H*W) % 4 == 0, x_bs % 4 == 0, 16-byte aligned x;
+ * returns SGTA_EBADARG otherwise (callers then use sgta_conv2d_f32). */
+int sgta_conv1x1_f32(const float* x, long x_bs, const float* wt, const float* bias, const float* res,
+                     long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout, int Cout_pad,
+                     int Cin_pad, int act, int res_mode, sgta_stream_t stream);
+
 /* The 16-output-channel convs on the full-resolution maps (MFMA 16x16x4, whole input window + weights in LDS):
  *   mode 0: level0 = relu(bn(conv3x3(x [B,16,H,W])))                        (dla.py:246-247, :302-312); x2 = NULL
  *           wt [144][16] with k = c*9 + ky*3 + kx (BN scale folded), bias [16]

@@ -116,6 +116,14 @@ class PackedConv:
             wp[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
             self.wt_patch = wp.contiguous()
 
+        # 1x1: GEMM layout of sgta_conv1x1_f32, [Cin_pad/16][Cout_pad][20]
+        self.wt_1x1 = None
+        if kh == 1 and stride == 1 and not tap_major:
+            w1 = torch.zeros(self.Kpad // 16, self.Cout_pad, 20, dtype=torch.float32, device=w.device)
+            wf = torch.zeros(self.Cout_pad, self.Kpad, dtype=torch.float32, device=w.device)
+            wf[:co, :ci] = w.reshape(co, ci)
+            w1[:, :, :16] = wf.view(self.Cout_pad, self.Kpad // 16, 16).permute(1, 0, 2)
+            self.wt_1x1 = w1.contiguous()
         # Winograd F(2x2,3x3): U = G g G^T, packed [Cin/8][16][Cout_pad][8]
         self.u_wino = None
         if kh == 3 and stride == 1 and self.pad == 1 and ci % 8 == 0 and not tap_major:
@@ -205,6 +213,16 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         res = as_view(res)
         assert res_mode in (1, 2) and res.C == pc.Cout and res.H == out.H and res.W == out.W
         rp, rbs = res.ptr, res.bs
+    if (USE_CONV1X1 and pc.wt_1x1 is not None and tile == 0 and (x.H * x.W) % 4 == 0 and x.bs % 4 == 0
+            and x.ptr % 16 == 0):
+        meta = None
+        if _lib.PROFILE is not None:
+            meta = _conv_meta(pc, out, 2, False)
+            meta["kernel"] = "conv1x1_kernel<%d>" % (2 if pc.Cout_pad % 64 == 0 else 1)
+        _lib.call("sgta_conv1x1_f32", x.ptr, x.bs, pc.wt_1x1.data_ptr(), pc.bias.data_ptr(), rp, rbs, out.ptr,
+                  out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, pc.Kpad, act,
+                  res_mode if res is not None else 0, _stream(), meta=meta)
+        return out
     if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
         code = pc.wino_tile(x.H, x.W)
         meta = None
@@ -233,6 +251,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
 
 WINO_FORCE_MT1 = False         # tools: 32-cout Winograd tiles (two work-groups per CU) everywhere
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
+USE_CONV1X1 = True             # LDS-DMA GEMM kernel for 1x1 convs (False: generic implicit GEMM)
 USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)
 DCN_FORCE_MT = 0               # tools: force 64 (2) / 128 (4) couts per work-group
 USE_PATCH_KERNEL = True        # tools/tests flip this to time / check the generic implicit-GEMM path

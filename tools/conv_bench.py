@@ -23,6 +23,9 @@ SHAPES = [
     ("l4_3x3", "conv", 256, 256, 3, 1, 30, 40, 64),
     ("l5_3x3", "conv", 512, 512, 3, 1, 15, 20, 64),
     ("l3_root", "conv", 448, 128, 1, 1, 60, 80, 64),
+    ("l2_root", "conv", 128, 64, 1, 1, 120, 160, 64),
+    ("l5_root", "conv", 1280, 512, 1, 1, 15, 20, 64),
+    ("head_hm", "conv", 256, 7, 1, 1, 120, 160, 32),
     ("heads0", "conv", 64, 768, 3, 1, 120, 160, 32),
     ("om_64", "conv", 64, 27, 3, 1, 120, 160, 32),
     ("om_128", "conv", 128, 27, 3, 1, 60, 80, 32),
@@ -44,6 +47,7 @@ def main():
     a = ap.parse_args()
     dev = "cuda:0"
     ops.USE_PATCH_KERNEL = not a.generic
+    ops.USE_CONV1X1 = not a.generic
     ops.USE_WINOGRAD = not (a.generic or a.no_wino)
     ops.WINO_FORCE_MT1 = a.wino_mt1
     ops.USE_DCN_LDS_KERNEL = not a.generic
