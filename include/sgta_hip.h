@@ -79,6 +79,19 @@ int sgta_conv1x1_f32(const float* x, long x_bs, const float* wt, const float* bi
                      long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout, int Cout_pad,
                      int Cin_pad, int act, int res_mode, sgta_stream_t stream);
 
+/* 1x1 conv with Cout <= 8 (the output conv of each head, base_model.py:122-123): HBM-streaming kernel, one
+ * thread = 4 consecutive pixels.  w: plain [Cout][Cin] fp32, bias [Cout].  H*W % 4 == 0, x / y 16-byte aligned,
+ * batch strides % 4 == 0 (else SGTA_EBADARG: use sgta_conv1x1_f32 / sgta_conv2d_f32).  act: 0 none, 1 relu, 2 sigmoid. */
+int sgta_conv1x1_skinny_f32(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+                            int B, int Cin, int H, int W, int Cout, int act, sgta_stream_t stream);
+
+/* conv3x3 / stride 2 / pad 1 + folded BN + ReLU (first conv of the down-sampling BasicBlocks, level1;
+ * dla.py:44-46, :248-249): 2-D output tiles, de-interleaved input window staged by LDS-DMA.
+ * wt : packed [Cin/4][Cout_pad][36] (same layout as sgta_conv3x3s1_f32), Cin % 4 == 0.
+ * tile = 10*MT + t: MT in {1,2} = 32 / 64 output channels per work-group, t in {0,1,2} = 8x32 / 16x16 / 32x8 tiles. */
+int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y, long y_bs,
+                       int B, int Cin, int H, int W, int Cout, int Cout_pad, int tile, sgta_stream_t stream);
+
 /* The 16-output-channel convs on the full-resolution maps (MFMA 16x16x4, whole input window + weights in LDS):
  *   mode 0: level0 = relu(bn(conv3x3(x [B,16,H,W])))                        (dla.py:246-247, :302-312); x2 = NULL
  *           wt [144][16] with k = c*9 + ky*3 + kx (BN scale folded), bias [16]

@@ -175,3 +175,92 @@ extern "C" int sgta_conv1x1_f32(const float* x, long x_bs, const float* wt, cons
   if (act == 2 && res_mode == 0) return launch_c1<2, 0>(a, st);
   return SGTA_EBADARG;
 }
+
+// ---- "skinny" 1x1 conv: Cout <= 8 (the output conv of every head, base_model.py:122-123) --------------------
+// 7 / 2 / 2 output channels cannot fill an MFMA tile and the op is a pure stream over the hidden activations
+// (256 x HW floats in, <= 8 x HW out): one thread owns 4 consecutive pixels, walks the channel planes with
+// 16-byte loads (8 in flight per lane) and keeps Cout x 4 accumulators; the weights are wave-uniform scalar loads.
+template <int CO, int ACT>
+__global__ __launch_bounds__(128) void conv1x1_skinny_kernel(const float* __restrict__ x, long x_bs,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ y, long y_bs, int Cin, int HW,
+                                                             int quads_per_img, long nquads) {
+  constexpr int U = 8;
+  const long q = blockIdx.x * 128L + threadIdx.x;
+  if (q >= nquads) return;
+  const int b = (int)(q / quads_per_img);
+  const int p = (int)(q - (long)b * quads_per_img) * 4;
+  const float* xp = x + (long)b * x_bs + p;
+  f32x4 acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) { const float bo = bias[o]; acc[o] = f32x4{bo, bo, bo, bo}; }
+  int c = 0;
+  for (; c + U <= Cin; c += U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xp + (long)(c + u) * HW));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        const float wv = w[o * Cin + c + u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(wv, v[u][e], acc[o][e]);
+      }
+  }
+  for (; c < Cin; ++c) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (long)c * HW);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float wv = w[o * Cin + c];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[o][e] = fmaf(wv, v[e], acc[o][e]);
+    }
+  }
+  float* yp = y + (long)b * y_bs + p;
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    f32x4 r = acc[o];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (ACT == 1) r[e] = fmaxf(r[e], 0.0f);
+      if (ACT == 2) r[e] = sigmoidf_(r[e]);
+    }
+    *reinterpret_cast<f32x4*>(yp + (long)o * HW) = r;
+  }
+}
+
+template <int CO>
+static int launch_skinny(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs, int Cin,
+                         int HW, long nquads, int act, hipStream_t st) {
+  const int grid = (int)((nquads + 127) / 128);
+#define SGTA_SK(ACT) hipLaunchKernelGGL((conv1x1_skinny_kernel<CO, ACT>), dim3(grid), dim3(128), 0, st, x, x_bs, w, bias, y, y_bs, Cin, HW, HW / 4, nquads)
+  if (act == 0) SGTA_SK(0);
+  else if (act == 1) SGTA_SK(1);
+  else if (act == 2) SGTA_SK(2);
+  else return SGTA_EBADARG;
+#undef SGTA_SK
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}
+
+extern "C" int sgta_conv1x1_skinny_f32(const float* x, long x_bs, const float* w, const float* bias, float* y,
+                                       long y_bs, int B, int Cin, int H, int W, int Cout, int act,
+                                       hipStream_t st) {
+  if (!x || !w || !bias || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 8) return SGTA_EBADARG;
+  const int HW = H * W;
+  if (HW % 4 || x_bs % 4 || y_bs % 4 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return SGTA_EBADARG;
+  const long nquads = (long)B * (HW / 4);
+  if (nquads > 0x7fffffffL * 32) return SGTA_EBADARG;
+  switch (Cout) {
+    case 1: return launch_skinny<1>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    case 2: return launch_skinny<2>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    case 3: return launch_skinny<3>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    case 4: return launch_skinny<4>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    case 5: return launch_skinny<5>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    case 6: return launch_skinny<6>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    case 7: return launch_skinny<7>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+    default: return launch_skinny<8>(x, x_bs, w, bias, y, y_bs, Cin, HW, nquads, act, st);
+  }
+}

@@ -1,0 +1,179 @@
+// 3x3 / stride 2 / pad 1 convolution + folded BN + ReLU (the first conv of every down-sampling BasicBlock and
+// level1 of DLA-34; reference dla.py:44-46, :248-249, :302-312) for gfx950, f32 MFMA 32x32x2.
+// 2-D output tile of 256 pixels (TH x TW); the (2TH+1) x (2TW+1) input window of 4 channels at a time is
+// staged by LDS-DMA (double buffered, zero-filled outside the image) with its columns DE-INTERLEAVED
+// ([even | odd], padded so that the tile rows of a 32-lane group hit disjoint banks): the stride-2 reads of
+// neighbouring output pixels become unit-stride and conflict-free.  Lane half = channel of a pair, the nine
+// k-steps of a pair are the taps (as in conv3x3_patch.hip).
+#include "common.h"
+
+struct S2Args {
+  const float* x;  long x_bs;
+  const float* wt;                 // [Cin/4][Cout_pad][36], k_local = c_local*9 + tap
+  const float* bias;               // [Cout_pad]
+  float* y;        long y_bs;
+  int B, Cin, H, W, Ho, Wo, Cout, Cout_pad;
+  int nchunks, tiles_x, tiles_y, n_ct, n_pt;
+};
+
+__device__ float sgta_s2_zero = 0.0f;
+
+__host__ __device__ constexpr int s2_wwp(int TW) { return TW == 8 ? 20 : (TW == 16 ? 40 : 2 * TW + 2); }
+
+template <int MT, int TW>
+__global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
+  constexpr int NT = 2, BM = MT * 32, TH = 256 / TW, CK = 4;
+  constexpr int WH = 2 * TH + 1, WW = 2 * TW + 1, NE = TW + 1, WWP = s2_wwp(TW), WSZ = WH * WWP;
+  constexpr int KC = CK * 9, LDA = KC + 1;
+  constexpr int P_TOT = CK * WSZ, A_TOT = BM * LDA;
+  constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_TOT + 255) / 256;
+  constexpr int STAGE = (P_PER + A_PER) * 256;
+  __shared__ float lds[2 * STAGE + BM];
+  float* const sbias = lds + 2 * STAGE;
+
+  int pt, ct;
+  xcd_remap(blockIdx.x, a.n_ct, pt, ct);
+  if (pt >= a.n_pt) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int H = a.H, W = a.W, HW = H * W, HWo = a.Ho * a.Wo;
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int b = pt / tiles;
+  const int tr = pt - b * tiles;
+  const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;    // output tile origin
+  const int wy0 = 2 * ty0 - 1, wx0 = 2 * tx0 - 1;                        // input window origin
+  const float* xb = a.x + (long)b * a.x_bs;
+  if (tid < BM) sbias[tid] = a.bias[ct * BM + tid];
+
+  int poff[P_PER], aoff[A_PER];
+#pragma unroll
+  for (int t = 0; t < P_PER; ++t) {
+    const int e = tid + t * 256;
+    const int c = e / WSZ, r = e - c * WSZ;
+    const int sx = r % WWP;
+    const int col = sx < NE ? 2 * sx : 2 * (sx - NE) + 1;
+    const int gy = wy0 + r / WWP, gx = wx0 + col;
+    const bool ok = e < P_TOT && sx < WW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    poff[t] = ok ? c * HW + gy * W + gx : -1;
+  }
+#pragma unroll
+  for (int t = 0; t < A_PER; ++t) {
+    const int e = tid + t * 256;
+    const int row = e / LDA, col = e - row * LDA;
+    aoff[t] = (e < A_TOT && col < KC) ? row * KC + col : -1;
+  }
+  auto stage = [&](int kc, int st) {
+    float* dst = lds + st * STAGE + wave * 64;
+    const float* xc = xb + (long)kc * CK * HW;
+#pragma unroll
+    for (int t = 0; t < P_PER; ++t)
+      __builtin_amdgcn_global_load_lds(poff[t] >= 0 ? xc + poff[t] : &sgta_s2_zero, dst + t * 256, 4, 0, 0);
+    const float* src = a.wt + ((long)kc * a.Cout_pad + ct * BM) * KC;
+    float* adst = dst + P_PER * 256;
+#pragma unroll
+    for (int t = 0; t < A_PER; ++t)
+      __builtin_amdgcn_global_load_lds(aoff[t] >= 0 ? src + aoff[t] : &sgta_s2_zero, adst + t * 256, 4, 0, 0);
+  };
+
+  int tbase[NT], oy[NT], ox[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int pl = (wave * NT + j) * 32 + l31;
+    const int ty = pl / TW, tx = pl % TW;
+    oy[j] = ty0 + ty; ox[j] = tx0 + tx;
+    tbase[j] = (2 * ty) * WWP + tx;
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kc = 0; kc < a.nchunks; ++kc) {
+    const int st = kc & 1;
+    if (kc + 1 < a.nchunks) stage(kc + 1, st ^ 1);
+    const float* win = lds + st * STAGE;
+    const float* As = win + P_PER * 256;
+#pragma unroll
+    for (int q = 0; q < CK / 2; ++q) {
+      const float* prow = win + (2 * q + lh) * WSZ;
+      const float* arow = As + l31 * LDA + (2 * q + lh) * 9;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        constexpr int dummy = 0; (void)dummy;
+        const int ky = tap / 3, kx = tap % 3;
+        const int toff = ky * WWP + (kx & 1) * NE + (kx >> 1);
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = arow[i * 32 * LDA + tap];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = prow[tbase[j] + toff];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (oy[j] >= a.Ho || ox[j] >= a.Wo) continue;
+    float* yb = a.y + (long)b * a.y_bs + oy[j] * a.Wo + ox[j];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = i * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+        const int co = ct * BM + cl;
+        const float v = fmaxf(acc[i][j][r] + sbias[cl], 0.0f);
+        if (co < a.Cout) yb[(long)co * HWo] = v;
+      }
+  }
+}
+
+extern "C" int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y,
+                                  long y_bs, int B, int Cin, int H, int W, int Cout, int Cout_pad, int tile,
+                                  hipStream_t st) {
+  if (!x || !wt || !bias || !y || B <= 0 || Cin <= 0 || H < 2 || W < 2 || Cout <= 0) return SGTA_EBADARG;
+  if (Cin % 4 || Cout_pad % 32 || Cout_pad < Cout || (long)Cin * H * W > 0x7fffffffL) return SGTA_EBADARG;
+  S2Args a{};
+  a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.y = y; a.y_bs = y_bs;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+  a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 4;
+  auto go = [&](auto kern, int BM, int TW) -> int {
+    const int TH = 256 / TW;
+    a.n_ct = a.Cout_pad / BM;
+    a.tiles_x = cdiv(a.Wo, TW);
+    a.tiles_y = cdiv(a.Ho, TH);
+    a.n_pt = a.B * a.tiles_x * a.tiles_y;
+    int grid = cdiv(a.n_pt, 8) * 8 * a.n_ct;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+    SGTA_LAUNCH_CHECK();
+    return SGTA_OK;
+  };
+  // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2} = 8x32 / 16x16 / 32x8 output tiles
+  const int mt = tile / 10, tw = tile % 10;
+  if (mt == 2 && Cout_pad % 64 == 0) {
+    if (tw == 0) return go(conv3x3_s2_kernel<2, 32>, 64, 32);
+    if (tw == 1) return go(conv3x3_s2_kernel<2, 16>, 64, 16);
+    if (tw == 2) return go(conv3x3_s2_kernel<2, 8>, 64, 8);
+  }
+  if (mt == 1) {
+    if (tw == 0) return go(conv3x3_s2_kernel<1, 32>, 32, 32);
+    if (tw == 1) return go(conv3x3_s2_kernel<1, 16>, 32, 16);
+    if (tw == 2) return go(conv3x3_s2_kernel<1, 8>, 32, 8);
+  }
+  return SGTA_EBADARG;
+}

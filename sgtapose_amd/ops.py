@@ -111,7 +111,7 @@ class PackedConv:
         self._ktab = {}
         # 3x3 / stride 1 / pad 1: second layout for the LDS-patch kernel, [Cin/4][Cout_pad][36]
         self.wt_patch = None
-        if kh == 3 and stride == 1 and self.pad == 1 and ci % 4 == 0 and not tap_major:
+        if kh == 3 and stride in (1, 2) and self.pad == 1 and ci % 4 == 0 and not tap_major:
             wp = torch.zeros(ci // 4, self.Cout_pad, 36, dtype=torch.float32, device=w.device)
             wp[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
             self.wt_patch = wp.contiguous()
@@ -124,6 +124,11 @@ class PackedConv:
             wf[:co, :ci] = w.reshape(co, ci)
             w1[:, :, :16] = wf.view(self.Cout_pad, self.Kpad // 16, 16).permute(1, 0, 2)
             self.wt_1x1 = w1.contiguous()
+        # 1x1 with <= 8 outputs (head output convs): plain [Cout][Cin] rows for sgta_conv1x1_skinny_f32
+        self.w_skinny = None
+        if kh == 1 and stride == 1 and co <= 8 and not tap_major:
+            self.w_skinny = w.reshape(co, ci).contiguous()
+            self.b_skinny = self.bias[:co].contiguous()
         # Winograd F(2x2,3x3): U = G g G^T, packed [Cin/8][16][Cout_pad][8]
         self.u_wino = None
         if kh == 3 and stride == 1 and self.pad == 1 and ci % 8 == 0 and not tap_major:
@@ -152,6 +157,18 @@ class PackedConv:
                 best = (mt * 10 + code, util)
         return best
 
+    def s2_tile(self, H, W):
+        """Tile code for sgta_conv3x3s2_f32: best-filling 256-pixel output tile."""
+        mt = 2 if self.Cout_pad % 64 == 0 else 1
+        ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        best = None
+        for code, tw in ((0, 32), (1, 16), (2, 8)):
+            th = 256 // tw
+            util = (ho * wo) / float((-(-wo // tw) * tw) * (-(-ho // th) * th))
+            if best is None or util > best[1] + 1e-9:
+                best = (mt * 10 + code, util)
+        return best[0] if best[1] >= 0.7 else 0          # poorly filled tiles: generic implicit GEMM wins
+
     def wino_tile(self, H, W):
         """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape."""
         mt = 2 if (self.Cout_pad % 64 == 0 and not WINO_FORCE_MT1) else 1
@@ -166,7 +183,7 @@ class PackedConv:
 
     def patch_tile(self, W, tile=0, HW=None):
         """Tile id for sgta_conv3x3s1_f32, or 0 when that kernel does not cover (W, tile)."""
-        if self.wt_patch is None:
+        if self.wt_patch is None or self.stride != 1:
             return 0
         if tile == 0:
             # measured (tools/conv_bench.py): 64x256 is the fastest tile whenever it applies; small
@@ -213,6 +230,15 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         res = as_view(res)
         assert res_mode in (1, 2) and res.C == pc.Cout and res.H == out.H and res.W == out.W
         rp, rbs = res.ptr, res.bs
+    if (USE_CONV1X1 and pc.w_skinny is not None and tile == 0 and res is None and (x.H * x.W) % 4 == 0
+            and x.bs % 4 == 0 and out.bs % 4 == 0 and x.ptr % 16 == 0 and out.ptr % 16 == 0):
+        meta = None
+        if _lib.PROFILE is not None:
+            meta = _conv_meta(pc, out, 2, False)
+            meta["kernel"] = "conv1x1_skinny_kernel<%d>" % pc.Cout
+        _lib.call("sgta_conv1x1_skinny_f32", x.ptr, x.bs, pc.w_skinny.data_ptr(), pc.b_skinny.data_ptr(), out.ptr,
+                  out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, act, _stream(), meta=meta)
+        return out
     if (USE_CONV1X1 and pc.wt_1x1 is not None and tile == 0 and (x.H * x.W) % 4 == 0 and x.bs % 4 == 0
             and x.ptr % 16 == 0):
         meta = None
@@ -222,6 +248,19 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         _lib.call("sgta_conv1x1_f32", x.ptr, x.bs, pc.wt_1x1.data_ptr(), pc.bias.data_ptr(), rp, rbs, out.ptr,
                   out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, pc.Kpad, act,
                   res_mode if res is not None else 0, _stream(), meta=meta)
+        return out
+    if (USE_S2_KERNEL and pc.ks == 3 and pc.stride == 2 and pc.wt_patch is not None and tile == 0
+            and act == ACT_RELU and res is None):
+        code = pc.s2_tile(x.H, x.W)
+    else:
+        code = 0
+    if code:
+        meta = None
+        if _lib.PROFILE is not None:
+            meta = _conv_meta(pc, out, 2, False)
+            meta["kernel"] = "conv3x3_s2_kernel<%d,%d>" % (code // 10, (32, 16, 8)[code % 10])
+        _lib.call("sgta_conv3x3s2_f32", x.ptr, x.bs, pc.wt_patch.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
+                  x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, code, _stream(), meta=meta)
         return out
     if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
         code = pc.wino_tile(x.H, x.W)
@@ -251,6 +290,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
 
 WINO_FORCE_MT1 = False         # tools: 32-cout Winograd tiles (two work-groups per CU) everywhere
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
+USE_S2_KERNEL = True           # LDS-window kernel for 3x3 stride-2 convs (False: generic implicit GEMM)
 USE_CONV1X1 = True             # LDS-DMA GEMM kernel for 1x1 convs (False: generic implicit GEMM)
 USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)
 DCN_FORCE_MT = 0               # tools: force 64 (2) / 128 (4) couts per work-group

@@ -85,6 +85,46 @@ def test_conv3x3_three_implementations_agree(ops, cin, cout, H, W):
         ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = flags
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(16, 32, 48, 64), (64, 128, 24, 40), (256, 512, 30, 40), (32, 64, 17, 23)])
+def test_conv3x3_stride2_kernel(ops, cin, cout, H, W):
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, bias, stride=2, padding=1))
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV), stride=2)
+    out = torch.empty(ref.shape, device=DEV)
+    for flag in (True, False):
+        old, ops.USE_S2_KERNEL = ops.USE_S2_KERNEL, flag
+        try:
+            out.zero_()
+            ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU)
+        finally:
+            ops.USE_S2_KERNEL = old
+        assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), flag
+
+
+@pytest.mark.parametrize("cin,cout,H,W,act", [(256, 7, 24, 40, 2), (256, 2, 24, 40, 0), (64, 5, 10, 14, 1), (100, 8, 6, 6, 0),
+                                              (128, 64, 24, 40, 1), (192, 96, 12, 20, 0), (256, 7, 9, 11, 2)])
+def test_conv1x1_gemm_and_skinny_kernels(ops, cin, cout, H, W, act):
+    g = torch.Generator().manual_seed(cin * cout + H)
+    x = torch.randn(3, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, bias)
+    ref = {0: ref, 1: F.relu(ref), 2: torch.sigmoid(ref)}[act]
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV))
+    out = torch.empty(ref.shape, device=DEV)
+    for flag in (True, False):          # dedicated 1x1 kernels, then the generic implicit GEMM
+        old, ops.USE_CONV1X1 = ops.USE_CONV1X1, flag
+        try:
+            out.zero_()
+            ops.conv2d(x.to(DEV), pc, out, act)
+        finally:
+            ops.USE_CONV1X1 = old
+        assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), flag
+
+
 def test_conv_c16_level0_and_fused_stems(ops):
     g = torch.Generator().manual_seed(21)
     bn = lambda: (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1,

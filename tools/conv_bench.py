@@ -18,6 +18,9 @@ SHAPES = [
     ("stem_hm", "conv", 1, 16, 7, 1, 480, 640, 32),
     ("level0", "conv", 16, 16, 3, 1, 480, 640, 64),
     ("level1", "conv", 16, 32, 3, 2, 480, 640, 64),
+    ("l2_s2", "conv", 32, 64, 3, 2, 240, 320, 64),
+    ("l3_s2", "conv", 64, 128, 3, 2, 120, 160, 64),
+    ("l5_s2", "conv", 256, 512, 3, 2, 30, 40, 64),
     ("l2_3x3", "conv", 64, 64, 3, 1, 120, 160, 64),
     ("l3_3x3", "conv", 128, 128, 3, 1, 60, 80, 64),
     ("l4_3x3", "conv", 256, 256, 3, 1, 30, 40, 64),
@@ -48,6 +51,7 @@ def main():
     dev = "cuda:0"
     ops.USE_PATCH_KERNEL = not a.generic
     ops.USE_CONV1X1 = not a.generic
+    ops.USE_S2_KERNEL = not a.generic
     ops.USE_WINOGRAD = not (a.generic or a.no_wino)
     ops.WINO_FORCE_MT1 = a.wino_mt1
     ops.USE_DCN_LDS_KERNEL = not a.generic
