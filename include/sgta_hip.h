@@ -70,6 +70,14 @@ int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float
                           long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
                           int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
 
+/* Same operation, "all 16 positions in one wave" Winograd kernel (conv3x3_winor.hip): 4-wave work-groups of
+ * 64 tiles x 32 output channels, input / output transforms entirely in registers, two work-groups per CU.
+ * u : packed [Cin/8][8][Cout_pad][20] (16 positions p = 4*xi + nu of U = G g G^T, then 4 pad floats).
+ * tile in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2 output tiles. */
+int sgta_conv3x3_winor_f32(const float* x, long x_bs, const float* u, const float* bias, const float* res,
+                          long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
+                          int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
+
 /* 1x1 conv (+ bias, residual, activation) as a GEMM over the flattened pixels, both operands staged by
  * 16-byte LDS-DMA (Root / project convs, dla.py:157-175, :211-216; second conv of the heads,
  * base_model.py:122-123).  wt : packed [Cin_pad/16][Cout_pad][20], element (c/16, co, c%16) = W[co][c]*bn_scale[co]

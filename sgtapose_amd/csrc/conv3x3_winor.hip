@@ -1,0 +1,360 @@
+// Winograd F(2x2, 3x3) convolution, "all positions in one wave" formulation for gfx950 (3x3, stride 1, pad 1,
+// + folded BN bias, residual, activation; BasicBlocks, heads, DCN offset conv: reference dla.py:41-69,
+// base_model.py:121-135).  Same arithmetic as conv3x3_wino.hip (16 instead of 36 multiplies per 2x2 output
+// tile and channel), different ownership:
+//
+//   a wave owns 16 tiles x 32 output channels for ALL 16 Winograd positions: 32 accumulators of the
+//   f32 MFMA 16x16x4 (128 registers).  Lane (g = lane / 16, t = lane % 16) reads the raw 4x4 input window of
+//   tile t / channel 4s+g ONCE (16 LDS reads), forms the 16 transformed values B^T d B in registers (32 adds)
+//   and feeds them to 32 MFMAs -- 1 LDS read per position instead of 4.  After the K loop each lane already
+//   holds the 16 position values of its (tile, 4 output channels): the output transform A^T m A, bias,
+//   residual, activation and the stores happen in registers, with no LDS round trip and no barrier.
+//
+// A work-group is only 4 waves (64 tiles x 32 output channels, <= 80 KB of LDS, 256 registers), so TWO
+// independent work-groups share a CU: one's prologue / epilogue hides behind the other's MFMA loop -- the
+// 30 % of conv3x3_wino.hip's time that its single 16-wave work-group per CU spends outside the loop.
+// U = G g G^T comes host-packed as [Cin/8][8][Cout_pad][16 positions + 4 pad]: a lane's A operands of a
+// k-step are 8 conflict-free ds_read_b128 (80-byte rows).  Window and U chunk arrive by LDS-DMA (2 stages).
+#include "common.h"
+
+struct WinoRArgs {
+  const float* x;  long x_bs;
+  const float* u;                  // [Cin/8][8][Cout_pad][20]
+  const float* bias;               // [Cout_pad]
+  const float* res; long res_bs;
+  float* y;        long y_bs;
+  int B, Cin, H, W, Cout, Cout_pad;
+  int nchunks, blk_r, blk_c, n_ct, n_pt, vec2;
+};
+
+// de-interleaved window row length (see conv3x3_wino.hip): tile rows of a 16-lane group on disjoint banks
+__host__ __device__ constexpr int wr_wwp(int TC) { return TC == 4 ? 18 : (TC == 8 ? 20 : (TC == 16 ? 40 : 2 * TC + 2)); }
+// channel plane stride == 16 (mod 32): the two channels of a 32-lane group use disjoint bank halves
+__host__ __device__ constexpr int wr_pad16(int w) { return (w % 32) <= 16 ? w + 16 - (w % 32) : w + 48 - (w % 32); }
+
+template <int TC, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void conv3x3_winor_kernel(WinoRArgs a) {
+  constexpr int BM = 32, CK = 8, TR = 64 / TC;
+  constexpr int WH = 2 * TR + 2, WW = 2 * TC + 2, NE = WW / 2, WWP = wr_wwp(TC);
+  constexpr int WSZ = WH * WWP, WSZP = wr_pad16(WSZ), ROUNDS = (WSZP + 255) / 256;
+  constexpr int LDU = 20, U_F = CK * BM * LDU, U_PER = U_F / 4 / 256;
+  static_assert(U_F % 1024 == 0, "U stage must be a whole number of 256 x 16-byte slots");
+  constexpr int STAGE = CK * WSZP + U_F;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  // PERSISTENT work-groups: gridDim.x = 2 x CUs; logical ids are consecutive inside an XCD, and a work-group
+  // walks the items id, id + G, id + 2G ... (item = (pixel block, 32-channel group), channel group fastest: the
+  // groups of one pixel block run side by side on one XCD and share the window in its L2).  The (item, chunk)
+  // pairs form ONE continuous stream through the 2-stage LDS ring: chunk 0 of the next item is in flight while
+  // the last chunk and the register epilogue of the current one run.
+  const int G = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int n_items = a.n_pt * a.n_ct;
+  if (wg >= n_items) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, tl = lane & 15;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int blks = a.blk_r * a.blk_c;
+  const int t = wave * 16 + tl;                      // this lane's tile inside the 64-tile block
+  const int trow = t / TC, tcol = t % TC;
+  const int tbase = (2 * trow) * WWP + tcol;
+  const int poffl = tbase + g * WSZP, uoffl = CK * WSZP + (g * BM + tl) * LDU;
+
+  // ---- LDS-DMA staging through buffer loads: per-slot byte offsets are chunk- and channel-invariant VGPRs,
+  // the channel / chunk advance is a scalar offset, and out-of-image slots carry an out-of-range offset that
+  // the buffer bounds check turns into zeros: no vector instruction is spent on addressing inside the loop.
+  unsigned poff[ROUNDS], uoff[U_PER];
+  int slot_r[ROUNDS], slot_c[ROUNDS];                // item-invariant window coordinates of this thread's slots
+#pragma unroll
+  for (int q = 0; q < ROUNDS; ++q) {
+    // the last round is shifted back to end exactly at WSZP (it re-writes a few slots of the previous round
+    // with identical data): every DMA runs with all 256 lanes, no divergent control flow around M0
+    const int e = tid + (q < ROUNDS - 1 ? q * 256 : WSZP - 256);
+    const int r = e / WWP, sx = e - r * WWP;
+    const bool ok = e < WSZ && sx < WW;
+    slot_r[q] = ok ? r - 1 : -0x10000;
+    slot_c[q] = (sx < NE ? 2 * sx : 2 * (sx - NE) + 1) - 1;
+  }
+  int uslot[U_PER];
+#pragma unroll
+  for (int q = 0; q < U_PER; ++q) {
+    const int e = tid + q * 256;                     // 16-byte slot: channel c = e / (BM*5), then (co, quarter)
+    const int c = e / (BM * 5), rem = e - c * (BM * 5);
+    uslot[q] = (c * a.Cout_pad * LDU + rem * 4) * 4;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t xrs;
+  const __amdgpu_buffer_rsrc_t urs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), (short)0, a.Cin * a.Cout_pad * LDU * 4, 0x00020000);
+#endif
+  // per-item staging parameters (scalar item -> image, block origin, channel group)
+  auto setup = [&](int item) {
+    const int pt = item / a.n_ct, ct = item - pt * a.n_ct;
+    const int b = pt / blks, rem = pt - b * blks;
+    const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
+    const int oy0 = 2 * br * TR, ox0 = 2 * bc * TC;
+#pragma unroll
+    for (int q = 0; q < ROUNDS; ++q) {
+      const int gy = oy0 + slot_r[q], gx = ox0 + slot_c[q];
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      poff[q] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+    }
+#pragma unroll
+    for (int q = 0; q < U_PER; ++q) uoff[q] = (unsigned)(uslot[q] + ct * BM * LDU * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.x_bs), (short)0, a.Cin * HW * 4,
+                                            0x00020000);
+#endif
+  };
+  // one chunk = three DMA batches (window channels 0-3, window channels 4-7, U) so that the issue can be
+  // spread between the MFMA groups of the previous chunk instead of one 21-instruction burst behind the barrier
+  auto stage = [&](int kc, int st, int part) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (part < 2) {
+      float* dst = lds + st * STAGE + wave * 64;
+#pragma unroll
+      for (int c = part * (CK / 2); c < (part + 1) * (CK / 2); ++c)
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + c * WSZP + (q < ROUNDS - 1 ? q * 256 : WSZP - 256)),
+                                                   4, poff[q], (kc * CK + c) * HW * 4, 0, 0);
+    } else {
+      float* udst = lds + st * STAGE + CK * WSZP + wave * 256;
+#pragma unroll
+      for (int q = 0; q < U_PER; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + q * 1024), 16, uoff[q],
+                                                 kc * CK * a.Cout_pad * LDU * 4, 0, 0);
+    }
+#endif
+  };
+
+  f32x4 acc[16][2];
+  // operand registers, software-pipelined by hand: positions 0..7 use uA, 8..15 use uB; d = raw 4x4 window
+  f32x4 uA[2][2], uB[2][2];
+  float d[4][4], V[16];
+  auto load_d = [&](const float* prow) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[r][j] = prow[r * WWP + (j & 1) * NE + (j >> 1)];
+  };
+  auto load_u = [&](f32x4 (&u)[2][2], const float* urow, int half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) u[i][v] = *reinterpret_cast<const f32x4*>(urow + i * 16 * LDU + (half * 2 + v) * 4);
+  };
+  // V = B^T d B :  rows then columns (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+  auto transform = [&]() {
+    float tr[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tr[0][j] = d[0][j] - d[2][j];
+      tr[1][j] = d[1][j] + d[2][j];
+      tr[2][j] = d[2][j] - d[1][j];
+      tr[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      V[xi * 4 + 0] = tr[xi][0] - tr[xi][2];
+      V[xi * 4 + 1] = tr[xi][1] + tr[xi][2];
+      V[xi * 4 + 2] = tr[xi][2] - tr[xi][1];
+      V[xi * 4 + 3] = tr[xi][1] - tr[xi][3];
+    }
+  };
+  auto mfma8 = [&](const f32x4 (&u)[2][2], int half) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[half * 8 + q][i] =
+            __builtin_amdgcn_mfma_f32_16x16x4f32(u[i][q >> 2][q & 3], V[half * 8 + q], acc[half * 8 + q][i], 0, 0, 0);
+  };
+
+  int item = wg, sidx = 0;
+  setup(item);
+  stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  load_d(lds + poffl);
+  load_u(uA, lds + uoffl, 0);
+
+  while (true) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ct = item % a.n_ct;
+    f32x4 bsv[2];                                     // bias of this lane's 8 output channels (i*16 + 4g + r)
+    bool more = true;
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+      const bool last = kc + 1 >= a.nchunks;
+      int nkc = kc + 1;
+      if (last) {
+        // last chunk of the item: its staging registers are free -> point them at the next item and put that
+        // item's first chunk in flight; fetch the bias for the epilogue
+        more = item + G < n_items;
+        nkc = 0;
+        if (more) setup(item + G);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bsv[i] = *reinterpret_cast<const f32x4*>(a.bias + ct * BM + i * 16 + 4 * g);
+      }
+      const bool dma = more;
+      if (dma) stage(nkc, sidx ^ 1, 0);
+      const float* P0 = lds + sidx * STAGE + poffl;
+      const float* U0 = lds + sidx * STAGE + uoffl;
+      // ---- k-step 0 (channels g of the chunk) ----
+      load_u(uB, U0, 1);
+      transform();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uA, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma) stage(nkc, sidx ^ 1, 1);
+      load_d(P0 + 4 * WSZP);                                // k-step 1 operands fly under the next 16 MFMAs
+      load_u(uA, U0 + 4 * BM * LDU, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma) stage(nkc, sidx ^ 1, 2);
+      // ---- k-step 1 (channels 4 + g) ----
+      load_u(uB, U0 + 4 * BM * LDU, 1);
+      transform();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uA, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // every LDS read of this stage has returned; the next chunk has landed once all waves pass the barrier
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      sidx ^= 1;
+      if (more) {                                           // first operands of the next chunk (or next item)
+        load_d(lds + sidx * STAGE + poffl);
+        load_u(uA, lds + sidx * STAGE + uoffl, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- output transform in registers: lane = tile t, output channels i*16 + 4g + r -----------------------
+    {
+      const int pt = item / a.n_ct;
+      const int b = pt / blks, rem = pt - b * blks;
+      const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
+      const int oy = 2 * br * TR + 2 * trow, ox = 2 * bc * TC + 2 * tcol;
+      if (oy < H && ox < W) {
+        const bool x1 = ox + 1 < W, y1 = oy + 1 < H;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = ct * BM + i * 16 + 4 * g + r;
+            if (co >= a.Cout) continue;
+            float ra[4], rb[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+              ra[xi] = (acc[xi * 4 + 0][i][r] + acc[xi * 4 + 1][i][r]) + acc[xi * 4 + 2][i][r];
+              rb[xi] = (acc[xi * 4 + 1][i][r] - acc[xi * 4 + 2][i][r]) - acc[xi * 4 + 3][i][r];
+            }
+            const float bs = bsv[i][r];
+            float v[4] = {(ra[0] + ra[1]) + ra[2] + bs, (rb[0] + rb[1]) + rb[2] + bs,
+                          (ra[1] - ra[2]) - ra[3] + bs, (rb[1] - rb[2]) - rb[3] + bs};
+            const long o = (long)co * HW + oy * W + ox;
+            float* yp = a.y + (long)b * a.y_bs + o;
+            float rr4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (RES) {
+              const float* rp = a.res + (long)b * a.res_bs + o;
+              if (a.vec2) {
+                const float2 q0 = *reinterpret_cast<const float2*>(rp);
+                rr4[0] = q0.x; rr4[1] = q0.y;
+                if (y1) { const float2 q1 = *reinterpret_cast<const float2*>(rp + W); rr4[2] = q1.x; rr4[3] = q1.y; }
+              } else {
+                rr4[0] = rp[0];
+                if (x1) rr4[1] = rp[1];
+                if (y1) rr4[2] = rp[W];
+                if (x1 && y1) rr4[3] = rp[W + 1];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (RES == 1) v[q] += rr4[q];
+              if (ACT == 1) v[q] = fmaxf(v[q], 0.0f);
+              if (ACT == 2) v[q] = sigmoidf_(v[q]);
+              if (RES == 2) v[q] += rr4[q];
+            }
+            if (a.vec2) {
+              *reinterpret_cast<float2*>(yp) = float2{v[0], v[1]};
+              if (y1) *reinterpret_cast<float2*>(yp + W) = float2{v[2], v[3]};
+            } else {
+              yp[0] = v[0];
+              if (x1) yp[1] = v[1];
+              if (y1) yp[W] = v[2];
+              if (x1 && y1) yp[W + 1] = v[3];
+            }
+          }
+      }
+    }
+    if (!more) break;
+    item += G;
+  }
+}
+
+template <int ACT, int RES>
+static int launch_winor(WinoRArgs& a, int tile, hipStream_t st) {
+  auto go = [&](auto kern, int TC) -> int {
+    const int TR = 64 / TC;
+    a.n_ct = a.Cout_pad / 32;
+    a.blk_r = cdiv(cdiv(a.H, 2), TR);
+    a.blk_c = cdiv(cdiv(a.W, 2), TC);
+    a.n_pt = a.B * a.blk_r * a.blk_c;
+    // persistent: as many work-groups as the device holds at once (2 per CU), never more than items
+    static int resident_by_tile[4] = {0, 0, 0, 0};          // per <ACT, RES> instance and tile shape
+    int& resident = resident_by_tile[tile];
+    if (!resident) {
+      int dev = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+        return SGTA_EBADARG;
+      resident = cus * per_cu;
+    }
+    const long items = (long)a.n_pt * a.n_ct;
+    int grid = (int)(items < resident ? items : resident);
+    grid = cdiv(grid, 8) * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+    SGTA_LAUNCH_CHECK();
+    return SGTA_OK;
+  };
+  // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2 output tiles
+  switch (tile) {
+    case 0: return go(conv3x3_winor_kernel<32, ACT, RES>, 32);
+    case 1: return go(conv3x3_winor_kernel<16, ACT, RES>, 16);
+    case 2: return go(conv3x3_winor_kernel<8, ACT, RES>, 8);
+    case 3: return go(conv3x3_winor_kernel<4, ACT, RES>, 4);
+  }
+  return SGTA_EBADARG;
+}
+
+extern "C" int sgta_conv3x3_winor_f32(const float* x, long x_bs, const float* u, const float* bias,
+                                      const float* res, long res_bs, float* y, long y_bs, int B, int Cin,
+                                      int H, int W, int Cout, int Cout_pad, int act, int res_mode, int tile,
+                                      hipStream_t st) {
+  if (!x || !u || !bias || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SGTA_EBADARG;
+  if (Cin % 8 || Cout_pad % 32 || Cout_pad < Cout) return SGTA_EBADARG;
+  if ((res_mode != 0) != (res != nullptr) || (long)Cin * H * W > 0x7fffffffL) return SGTA_EBADARG;
+  // buffer descriptors (LDS-DMA with hardware bounds check) address one image / the packed U in 31 bits
+  if ((long)Cin * H * W * 4 > 0x7fffffffL || (long)Cin * Cout_pad * 80 > 0x7fffffffL) return SGTA_EBADARG;
+  WinoRArgs a{};
+  a.x = x; a.x_bs = x_bs; a.u = u; a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 8;
+  // 8-byte row-pair stores / residual loads need even widths and 8-byte aligned planes
+  a.vec2 = (W % 2 == 0) && (y_bs % 2 == 0) && (((uintptr_t)y & 7) == 0) &&
+           (!res || ((res_bs % 2 == 0) && (((uintptr_t)res & 7) == 0)));
+  if (act == 1 && res_mode == 0) return launch_winor<1, 0>(a, tile, st);
+  if (act == 0 && res_mode == 0) return launch_winor<0, 0>(a, tile, st);
+  if (act == 1 && res_mode == 1) return launch_winor<1, 1>(a, tile, st);
+  if (act == 1 && res_mode == 2) return launch_winor<1, 2>(a, tile, st);
+  if (act == 2 && res_mode == 0) return launch_winor<2, 0>(a, tile, st);
+  return SGTA_EBADARG;
+}

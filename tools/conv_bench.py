@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--generic", action="store_true", help="force the implicit-GEMM gather kernel")
     ap.add_argument("--wino-mt1", action="store_true", help="32-cout Winograd tiles")
+    ap.add_argument("--wino-lds", action="store_true", help="wave-per-position Winograd kernel (conv3x3_wino.hip)")
     ap.add_argument("--no-wino", action="store_true", help="direct (LDS-range) 3x3 kernel instead of Winograd")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -54,10 +55,11 @@ def main():
     ops.USE_S2_KERNEL = not a.generic
     ops.USE_WINOGRAD = not (a.generic or a.no_wino)
     ops.WINO_FORCE_MT1 = a.wino_mt1
+    ops.WINO_REG = not a.wino_lds
     ops.USE_DCN_LDS_KERNEL = not a.generic
     tiles = [int(t) for t in a.tiles.split(",")]
     for name, kind, ci, co, ks, st, H, W, N in SHAPES:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         g = torch.Generator().manual_seed(1)
         x = torch.randn(N, ci, H, W, device=dev)
