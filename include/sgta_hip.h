@@ -124,7 +124,7 @@ int sgta_dcnv2_fwd_f32(const float* x, long x_bs, const float* om, long om_bs, c
  * pixels (TH x TW), stages the (TH+12) x (TW+12) window of 4 input channels at a time by LDS-DMA
  * (double buffered) and samples bilinearly from LDS (per-lane global fallback for samples that leave the window,
  * so the result does not depend on the window size).
- * wt : packed [Cin/4][Cout_pad][36], element (c/4, co, (c%4)*9 + ky*3 + kx); Cin % 4 == 0, Cout_pad % 64 == 0.
+ * wt : packed [Cin/4][36][Cout_pad], element (c/4, (c%4)*9 + ky*3 + kx, co); Cin % 4 == 0, Cout_pad % 64 == 0.
  * tile = 10*MT + t: MT in {2,4} = 64 / 128 output channels per work-group, t in {0,1,2} = 4x32 / 8x16 / 16x8 tiles. */
 int sgta_dcnv2_lds_f32(const float* x, long x_bs, const float* om, long om_bs, const float* wt,
                        const float* bias, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,

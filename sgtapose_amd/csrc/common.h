@@ -13,6 +13,7 @@
     if (e__ != hipSuccess) return (int)e__;         \
   } while (0)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -11,36 +11,32 @@
 // do not depend on R.  Loop order: channel chunk -> tap (sampling parameters computed once per tap) ->
 // channel pair (lane half 0/1 = channel 2q/2q+1 of the MFMA k-slot).
 #include "common.h"
+#include <type_traits>
 
 struct DcnArgs {
   const float* x;  long x_bs;
   const float* om; long om_bs;     // raw offset/mask conv output [B,27,H,W]
-  const float* wt;                 // [Cin/4][Cout_pad][36], k_local = c_local*9 + tap
+  const float* wt;                 // [Cin/4][36][Cout_pad], k_local = c_local*9 + tap (k-major rows)
   const float* bias;               // [Cout_pad]
   float* y;        long y_bs;
   int B, Cin, H, W, Cout, Cout_pad;
   int nchunks, tiles_x, tiles_y, n_ct, n_pt;
 };
 
-struct __attribute__((packed, aligned(4))) F2g { float a, b; };
-
-__device__ float sgta_zero_word = 0.0f;          // source of LDS-DMA slots that must read as zero
-
-// one 4-byte LDS-DMA: LDS destination = wave-uniform base + lane*4 (the builtin's contract)
-__device__ __forceinline__ void glds4(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
-}
 
 template <int MT, int NT, int TW, int R, int CK, int ACT>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
   constexpr int BM = MT * 32, TH = 128 * NT / TW;
   constexpr int PH = TH + 2 * R, PW = TW + 2 * R, PSZ = PH * PW;
-  constexpr int KC = CK * 9, LDA = KC + 1;
-  constexpr int P_TOT = CK * PSZ, A_TOT = BM * LDA;
-  constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_TOT + 255) / 256;
+  constexpr int KC = CK * 9;
+  // weights: k-major rows As[k][BM] (a lane's A operand = consecutive output channels: conflict-free), staged
+  // by 16-byte LDS-DMA; window: 4-byte LDS-DMA slots (arbitrary alignment of the image rows)
+  constexpr int P_TOT = CK * PSZ, A_SLOTS = KC * BM / 4;
+  constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_SLOTS + 255) / 256;
+  static_assert(A_SLOTS >= 256, "weight tile smaller than one DMA round");
   // ONE shared array (a second object beside an LDS-DMA target makes hipcc drain vmcnt early)
-  constexpr int STAGE = P_PER * 256 + A_PER * 256;            // floats per stage (slots rounded to 256)
-  __shared__ float lds[2 * STAGE + BM];
+  constexpr int STAGE = P_PER * 256 + KC * BM;                // floats per stage
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + BM];
   float* const sbias = lds + 2 * STAGE;
 
   int pt, ct;
@@ -58,34 +54,49 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
   const float* xb = a.x + (long)b * a.x_bs;
   if (tid < BM) sbias[tid] = a.bias[ct * BM + tid];
 
-  // ---- asynchronous staging of one channel chunk: window + weights, global -> LDS, no data registers.
-  // The per-slot source offsets do not depend on the chunk: computed once (-1 = slot reads as zero).
-  int poff[P_PER], aoff[A_PER];
+  // ---- asynchronous staging of one channel chunk: window + weights, global -> LDS through buffer loads:
+  // the per-slot byte offsets are chunk-invariant VGPRs, the chunk advance is a scalar offset, and slots
+  // outside the image carry an out-of-range offset that the buffer bounds check turns into zeros.
+  unsigned poff[P_PER], aoff[A_PER];
 #pragma unroll
   for (int t = 0; t < P_PER; ++t) {
     const int e = tid + t * 256;
     const int c = e / PSZ, r = e - c * PSZ;
     const int gy = win_y + r / PW, gx = win_x + r % PW;
     const bool ok = e < P_TOT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    poff[t] = ok ? c * HW + gy * W + gx : -1;
+    poff[t] = ok ? (unsigned)(c * HW + gy * W + gx) * 4u : 0x80000000u;
   }
 #pragma unroll
   for (int t = 0; t < A_PER; ++t) {
-    const int e = tid + t * 256;                   // LDS slot = row*LDA + col (col == KC is padding)
-    const int row = e / LDA, col = e - row * LDA;
-    aoff[t] = (e < A_TOT && col < KC) ? row * KC + col : -1;
+    // 16-byte slot e = (k, quarter): the last round is shifted back to end exactly at A_SLOTS (re-writing a few
+    // slots with identical data) so that every DMA runs with all 256 lanes
+    const int e = tid + (t < A_PER - 1 ? t * 256 : A_SLOTS - 256);
+    const int k = e / (BM / 4), s4 = e - k * (BM / 4);
+    aoff[t] = (unsigned)(k * a.Cout_pad + ct * BM + s4 * 4) * 4u;
   }
-  auto stage = [&](int kc, int st) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, a.Cin * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wt), (short)0, (a.Cin / CK) * KC * a.Cout_pad * 4, 0x00020000);
+#endif
+  // part 0 / 1: first / second half of the window slots, part 2: weights (spread between the k-steps)
+  auto stage = [&](int kc, int st, int part) {
+#if defined(__HIP_DEVICE_COMPILE__)
     float* dst = lds + st * STAGE + wave * 64;
-    const float* xc = xb + (long)kc * CK * HW;
+    if (part < 2) {
 #pragma unroll
-    for (int t = 0; t < P_PER; ++t)
-      glds4(poff[t] >= 0 ? xc + poff[t] : &sgta_zero_word, dst + t * 256);
-    const float* src = a.wt + ((long)kc * a.Cout_pad + ct * BM) * KC;
-    float* adst = dst + P_PER * 256;
+      for (int t = part * ((P_PER + 1) / 2); t < (part ? P_PER : (P_PER + 1) / 2); ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 256), 4, poff[t], kc * CK * HW * 4, 0, 0);
+    } else {
+      float* adst = lds + st * STAGE + P_PER * 256 + wave * 256;
 #pragma unroll
-    for (int t = 0; t < A_PER; ++t)
-      glds4(aoff[t] >= 0 ? src + aoff[t] : &sgta_zero_word, adst + t * 256);
+      for (int t = 0; t < A_PER; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + (t < A_PER - 1 ? t * 1024 : A_SLOTS * 4 - 1024)),
+                                                 16, aoff[t], kc * KC * a.Cout_pad * 4, 0, 0);
+    }
+#endif
   };
 
   // ---- this lane's two pixels and their 9 x 2 sampling parameter sets (kept in registers) -----------
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
     px[j] = tx0 + pl % TW;
     pvalid[j] = py[j] < H && px[j] < W;
   }
-  stage(0, 0);                                     // chunk 0 flies while the parameters are computed
+  stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2);  // chunk 0 flies while the parameters are computed
 
   unsigned plo[9][NT];                             // window offsets of the two row pairs: lo0 | lo1 << 16
   float pw[9][NT][4];
@@ -135,7 +146,11 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
       if (!inw) outmask |= 1u << (tap * NT + j);
     }
   }
-  const bool any_out = __any(outmask != 0);        // wave-uniform: the slow path is skipped entirely
+  unsigned wave_out = 0;                           // wave-uniform: bit set if ANY lane's sample leaves the window
+#pragma unroll
+  for (int bit = 0; bit < 9 * NT; ++bit)
+    if (__any((outmask >> bit) & 1u)) wave_out |= 1u << bit;
+  const bool any_out = wave_out != 0;              // the slow loop is skipped entirely for most waves
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -148,9 +163,15 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kc = 0; kc < a.nchunks; ++kc) {
+  // One channel chunk.  SLOW = some sample of this wave leaves the staged window and is fetched from global
+  // memory instead; the two variants are separate code so that the common (fast) loop contains LDS reads only
+  // -- a single merged loop made hipcc turn every gather into a FLAT load behind s_waitcnt vmcnt(0), i.e. every
+  // k-step waited for the LDS-DMA of the next chunk.
+  auto chunk = [&](int kc, auto slow_tag) {
+    constexpr bool SLOW = decltype(slow_tag)::value;
     const int st = kc & 1;
-    if (kc + 1 < a.nchunks) stage(kc + 1, st ^ 1);  // async: lands in the other stage during the MFMAs
+    const bool more = kc + 1 < a.nchunks;
+    if (more) stage(kc + 1, st ^ 1, 0);            // async: lands in the other stage during the MFMAs
     const float* patch = lds + st * STAGE;
     const float* Asm = patch + P_PER * 256;
     const float* xc = xb + (long)kc * CK * HW;
@@ -163,22 +184,30 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
       const int ch = 2 * q + lh;
       const float* prow = patch + ch * PSZ;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) av[slot][i] = Asm[(i * 32 + l31) * LDA + ch * 9 + tap];
+      for (int i = 0; i < MT; ++i) av[slot][i] = Asm[(ch * 9 + tap) * BM + i * 32 + l31];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int lo0 = plo[tap][j] & 0xffffu, lo1 = plo[tap][j] >> 16;
         float v00 = prow[lo0], v01 = prow[lo0 + 1], v10 = prow[lo1], v11 = prow[lo1 + 1];
-        if (any_out && ((outmask >> (tap * NT + j)) & 1u)) {   // rare: sample outside the staged window
-          const float* omp = a.om + (long)b * a.om_bs + py[j] * W + px[j];
-          const float sy = (float)(py[j] - 1 + tap / 3) + omp[(long)(2 * tap) * HW];
-          const float sx = (float)(px[j] - 1 + tap % 3) + omp[(long)(2 * tap + 1) * HW];
-          const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
-          const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
-          const int qx0 = min(max(x0, 0), W - 2);
-          const float* gp = xc + (long)ch * HW;
-          const F2g g0 = *reinterpret_cast<const F2g*>(gp + cy0 * W + qx0);
-          const F2g g1 = *reinterpret_cast<const F2g*>(gp + cy1 * W + qx0);
-          v00 = g0.a; v01 = g0.b; v10 = g1.a; v11 = g1.b;
+        if (SLOW) {
+          // wave-uniform test first: taps that no lane of the wave samples outside the window cost nothing
+          if ((wave_out >> (tap * NT + j)) & 1u) {
+            if ((outmask >> (tap * NT + j)) & 1u) {   // rare: sample outside the staged window
+              const float* omp = a.om + (long)b * a.om_bs + py[j] * W + px[j];
+              const float sy = (float)(py[j] - 1 + tap / 3) + omp[(long)(2 * tap) * HW];
+              const float sx = (float)(px[j] - 1 + tap % 3) + omp[(long)(2 * tap + 1) * HW];
+              const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+              const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+              const int qx0 = min(max(x0, 0), W - 2);
+              const float* g0 = xc + (long)ch * HW + cy0 * W + qx0;
+              const float* g1 = xc + (long)ch * HW + cy1 * W + qx0;
+              // opaque loads: a plain C++ load here gets merged with the LDS reads above into FLAT loads
+              f32x2 q0, q1;
+              asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                           : "=&v"(q0), "=&v"(q1) : "v"(g0), "v"(g1) : "memory");
+              v00 = q0[0]; v01 = q0[1]; v10 = q1[0]; v11 = q1[1];
+            }
+          }
         }
         float v = pw[tap][j][0] * v00;
         v = fmaf(pw[tap][j][1], v01, v);
@@ -190,6 +219,8 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
     fetch(0, 0);
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
+      if (step == NSTEP / 4 && more) stage(kc + 1, st ^ 1, 1);
+      if (step == NSTEP / 2 && more) stage(kc + 1, st ^ 1, 2);
       if (step + 1 < NSTEP) fetch(step + 1, (step + 1) & 1);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -199,6 +230,11 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage has landed (this wave's DMAs)
     __syncthreads();
+  };
+  if (any_out) {
+    for (int kc = 0; kc < a.nchunks; ++kc) chunk(kc, std::true_type{});
+  } else {
+    for (int kc = 0; kc < a.nchunks; ++kc) chunk(kc, std::false_type{});
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
@@ -233,18 +269,13 @@ static int launch_dcn_patch(DcnArgs& a, int tile, hipStream_t st) {
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   };
-  // tile = 10*MT + t:  MT in {2,4} = 64 / 128 output channels per work-group; 128-pixel 2-D tiles,
+  // tile = 10*MT + t:  MT = 2 = 64 output channels per work-group (128 measured slower); 128-pixel 2-D tiles,
   // t in {0,1,2} = 4x32 / 8x16 / 16x8 (rows x cols)
   const int mt = tile / 10, tw = tile % 10;
   if (mt == 2 && a.Cout_pad % 64 == 0) {
     if (tw == 0) return go(dcn_patch_kernel<2, 1, 32, R, CK, ACT>, 64, 1, 32);
     if (tw == 1) return go(dcn_patch_kernel<2, 1, 16, R, CK, ACT>, 64, 1, 16);
     if (tw == 2) return go(dcn_patch_kernel<2, 1, 8, R, CK, ACT>, 64, 1, 8);
-  }
-  if (mt == 4 && a.Cout_pad % 128 == 0) {
-    if (tw == 0) return go(dcn_patch_kernel<4, 1, 32, R, CK, ACT>, 128, 1, 32);
-    if (tw == 1) return go(dcn_patch_kernel<4, 1, 16, R, CK, ACT>, 128, 1, 16);
-    if (tw == 2) return go(dcn_patch_kernel<4, 1, 8, R, CK, ACT>, 128, 1, 8);
   }
   return SGTA_EBADARG;
 }
@@ -255,7 +286,8 @@ extern "C" int sgta_dcnv2_lds_f32(const float* x, long x_bs, const float* om, lo
                                   hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || B <= 0 || H <= 0 || W < 2 || Cout <= 0) return SGTA_EBADARG;
   if (Cin % 4 || Cout_pad % 64 || Cout_pad < Cout || act < 0 || act > 1) return SGTA_EBADARG;
-  if ((long)Cin * H * W > 0x7fffffffL) return SGTA_EBADARG;
+  // buffer descriptors (LDS-DMA with hardware bounds check) address one image / the packed weights in 31 bits
+  if ((long)Cin * H * W * 4 > 0x7fffffffL || (long)Cin * 9 * Cout_pad * 4 > 0x7fffffffL) return SGTA_EBADARG;
   DcnArgs a{};
   a.x = x; a.x_bs = x_bs; a.om = om; a.om_bs = om_bs; a.wt = wt; a.bias = bias; a.y = y; a.y_bs = y_bs;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 4;

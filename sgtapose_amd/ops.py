@@ -143,11 +143,11 @@ class PackedConv:
             ur = torch.zeros(ci // 8, 8, self.Cout_pad, 20, dtype=torch.float32, device=w.device)
             ur[:, :, :co, :16] = U.reshape(co, ci // 8, 8, 16).permute(1, 2, 0, 3)
             self.u_winor = ur.contiguous()
-        # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][Cout_pad][36] (k_local = c_local*9 + tap)
+        # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][36][Cout_pad] (k_local = c_local*9 + tap)
         self.wt_dcn8 = None
         if tap_major and kh == 3 and ci % 4 == 0 and self.Cout_pad % 64 == 0:
-            wd = torch.zeros(ci // 4, self.Cout_pad, 36, dtype=torch.float32, device=w.device)
-            wd[:, :co] = w.reshape(co, ci // 4, 36).permute(1, 0, 2)
+            wd = torch.zeros(ci // 4, 36, self.Cout_pad, dtype=torch.float32, device=w.device)
+            wd[:, :, :co] = w.reshape(co, ci // 4, 36).permute(1, 2, 0)
             self.wt_dcn8 = wd.contiguous()
 
     def dcn_tile(self, H, W):
@@ -309,7 +309,6 @@ WINO_REG = True                # Winograd: all-positions-per-wave kernel (False:
 USE_S2_KERNEL = True           # LDS-window kernel for 3x3 stride-2 convs (False: generic implicit GEMM)
 USE_CONV1X1 = True             # LDS-DMA GEMM kernel for 1x1 convs (False: generic implicit GEMM)
 USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)
-DCN_FORCE_MT = 0               # tools: force 64 (2) / 128 (4) couts per work-group
 USE_PATCH_KERNEL = True        # tools/tests flip this to time / check the generic implicit-GEMM path
 
 
@@ -378,8 +377,6 @@ def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     assert om.C == 27 and x.C == pc.Cin and out.C == pc.Cout
     if USE_DCN_LDS_KERNEL and pc.wt_dcn8 is not None and tile == 0:
         code, _ = pc.dcn_tile(x.H, x.W)
-        if DCN_FORCE_MT:
-            code = DCN_FORCE_MT * 10 + code % 10
         meta = None
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, True)

@@ -72,9 +72,6 @@ def main():
             def run(t, x=x, om=om, pc=pc, out=out):
                 if a.generic:
                     return ops.dcn_v2(x, om, pc, out, ops.ACT_RELU, tile=t)
-                ops.DCN_FORCE_MT = {1: 2, 2: 2, 3: 4}.get(t, 0)      # tile 2 -> 64 couts, 3 -> 128 couts
-                if ops.DCN_FORCE_MT == 4 and pc.Cout_pad % 128:
-                    raise ValueError
                 return ops.dcn_v2(x, om, pc, out, ops.ACT_RELU, tile=0)
         else:
             pc = ops.PackedConv(w, None, stride=st)
