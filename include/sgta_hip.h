@@ -62,19 +62,11 @@ int sgta_conv3x3s1_f32(const float* x, long x_bs, const float* wt, const float* 
 
 /* Same contract again (ks=3, stride=1, pad=1, Cin % 8 == 0) computed with Winograd F(2x2,3x3) in fp32:
  * 2.25x fewer MFMA cycles than the direct formulations; results differ from them at the 1e-6 level.
- * u : host-transformed weights G g G^T, packed [Cin/8][16][Cout_pad][8]: element (c/8, xi*4+nu, co, s) with
- *     the 8 channels of a chunk stored in the order s -> c%8 = 0,2,4,6,1,3,5,7.
- * tile = 10*MT + t: MT in {1,2} = 32 / 64 output channels per work-group (MT=2 needs Cout_pad % 64 == 0),
- * t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2-pixel tiles. */
+ * u : host-transformed weights U = G g G^T, packed [Cin/8][8][Cout_pad][20]: element (c/8, c%8, co, p) with the 16
+ *     positions p = 4*xi + nu first, then 4 pad floats (80-byte rows: conflict-free 16-byte LDS reads).
+ * tile in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2-pixel output tiles per work-group (64 tiles x 32
+ * output channels; persistent work-groups, two per CU).  One image (Cin*H*W*4 bytes) must fit 31 bits. */
 int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float* bias, const float* res,
-                          long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
-                          int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
-
-/* Same operation, "all 16 positions in one wave" Winograd kernel (conv3x3_winor.hip): 4-wave work-groups of
- * 64 tiles x 32 output channels, input / output transforms entirely in registers, two work-groups per CU.
- * u : packed [Cin/8][8][Cout_pad][20] (16 positions p = 4*xi + nu of U = G g G^T, then 4 pad floats).
- * tile in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2 output tiles. */
-int sgta_conv3x3_winor_f32(const float* x, long x_bs, const float* u, const float* bias, const float* res,
                           long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
                           int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
 

@@ -1,311 +1,407 @@
-// Winograd F(2x2, 3x3) convolution for gfx950 (3x3, stride 1, pad 1, + folded BN bias, residual,
-// activation): 16 multiplies per 2x2 output tile and channel pair instead of 36, i.e. 2.25x fewer
-// f32 MFMA cycles than any direct / implicit-GEMM formulation -- the f32 matrix pipe (157 TFLOP/s) is
-// what bounds this path, so the arithmetic itself is the lever.  Same layers as conv3x3_patch.hip
-// (BasicBlocks, heads, DCN offset conv; reference dla.py:41-69, base_model.py:121-135).
+// Winograd F(2x2, 3x3) convolution for gfx950 (3x3, stride 1, pad 1, + folded BN bias, residual, activation;
+// BasicBlocks, heads, DCN offset conv: reference dla.py:41-69, base_model.py:121-135): 16 multiplies per 2x2
+// output tile and channel instead of 36, i.e. 2.25x fewer f32 MFMA cycles than any direct / implicit-GEMM
+// formulation -- the f32 matrix pipe (157 TFLOP/s) bounds this path, so the arithmetic itself is the lever.
 //
 //   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A      per 2x2 output tile (d = 4x4 input tile)
 //
-// The 16 element-wise products are 16 independent GEMMs  M_p[co][tile] = sum_c U_p[co][c] V_p[c][tile].
-// A work-group = 16 waves = 1024 threads owns 64 tiles (TR x TC block = 2TR x 2TC output pixels) and
-// BM output channels; WAVE p OWNS POSITION p = (xi, nu), so every transformed input value V_p is
-// computed exactly once, on the fly, by the lane that feeds it to the MFMA: 4 LDS reads of the raw
-// input window + 3 adds (B^T has two +-1 entries per row; the (row pair, column pair, signs) of a
-// position are wave-uniform).  The lane half of the MFMA k-slot takes channel 2q / 2q+1.
-// U = G g G^T is precomputed on the host.  Input window and U chunk are staged by LDS-DMA (double
-// buffered, no registers).  After the K loop the 16 M_p tiles meet in LDS (the whole 160 KB is free
-// then) and 1024 threads apply A^T . A, bias, residual, activation and store 2x2 pixel tiles.
+// The 16 element-wise products are 16 independent GEMMs  M_p[co][tile] = sum_c U_p[co][c] V_p[c][tile]:
+//
+//   a wave owns 16 tiles x 32 output channels for ALL 16 Winograd positions: 32 accumulators of the
+//   f32 MFMA 16x16x4 (128 registers).  Lane (g = lane / 16, t = lane % 16) reads the raw 4x4 input window of
+//   tile t / channel 4s+g ONCE (16 LDS reads), forms the 16 transformed values B^T d B in registers (32 adds)
+//   and feeds them to 32 MFMAs -- 1 LDS read per position instead of 4.  After the K loop each lane already
+//   holds the 16 position values of its (tile, 4 output channels): the output transform A^T m A, bias,
+//   residual, activation and the stores happen in registers, with no LDS round trip and no barrier.
+//
+// A work-group is only 4 waves (64 tiles x 32 output channels, <= 80 KB of LDS, 256 registers), so TWO
+// independent, PERSISTENT work-groups share a CU and one's epilogue hides behind the other's MFMA loop.
+// U = G g G^T comes host-packed as [Cin/8][8][Cout_pad][16 positions + 4 pad]: a lane's A operands of a
+// k-step are 8 conflict-free ds_read_b128 (80-byte rows).  Window (stored de-interleaved [even | odd] columns so
+// that the stride-2 tile pattern reads unit-stride) and U chunk arrive by buffer LDS-DMA through a 2-stage ring.
 // fp32 throughout: the transforms only add and halve, error stays at the 1e-6 level (<< 1e-3).
 #include "common.h"
 
 struct WinoArgs {
   const float* x;  long x_bs;
-  const float* u;                  // [Cin/8][16][Cout_pad][8], channels of a chunk ordered 0,2,4,6,1,3,5,7
+  const float* u;                  // [Cin/8][8][Cout_pad][20]
   const float* bias;               // [Cout_pad]
   const float* res; long res_bs;
   float* y;        long y_bs;
   int B, Cin, H, W, Cout, Cout_pad;
-  int nchunks, blk_r, blk_c, n_ct, n_pt;
+  int nchunks, blk_r, blk_c, n_ct, n_pt, vec;      // vec: 4 / 2 / 1 pixels per store
 };
 
-__device__ float sgta_wino_zero = 0.0f;
-
-// 16-byte LDS-DMA.  The builtin's size-16 form only exists for gfx950; hipcc's HOST pass silently drops a
-// kernel template whose body mentions it, so the host pass must not see the call.
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-#endif
-}
-
-// padded, de-interleaved window row length: 2*WWP == 32/(32/TC) (mod 32) spreads the 32/TC tile rows of a
-// 32-lane group over disjoint bank ranges (TC = 4: WWP = 18, TC = 8: 20, TC = 16: 40, TC = 32: 66)
+// padded, de-interleaved window row length: 2*WWP == 32/(32/TC) (mod 32) puts the tile rows of a 16-lane group on
+// disjoint banks (TC = 4: WWP = 18, TC = 8: 20, TC = 16: 40, TC = 32: 66)
 __host__ __device__ constexpr int wino_wwp(int TC) { return TC == 4 ? 18 : (TC == 8 ? 20 : (TC == 16 ? 40 : 2 * TC + 2)); }
+// channel plane stride == 16 (mod 32): the two channels of a 32-lane group use disjoint bank halves
+__host__ __device__ constexpr int wino_pad16(int w) { return (w % 32) <= 16 ? w + 16 - (w % 32) : w + 48 - (w % 32); }
 
-// One chunk of one position (xi, nu).  The position is wave-uniform but a RUN-TIME value: a 16-way
-// switch over compile-time positions made hipcc spill >500 registers; uniform offsets / signs in
-// scalar registers cost one add per LDS read instead.
-//   xi = 0: d0 - d2 ; 1: d1 + d2 ; 2: d2 - d1 ; 3: d1 - d3      (same for nu over columns)
-template <int MT, int NT, int TC, int CK, int P_PER>
-__device__ __forceinline__ void wino_chunk(f32x16 (&acc)[MT][NT], const float* patch, const float* ul,
-                                           const int (&tbase)[NT], int lh, int o11, int o12, int o21, int o22,
-                                           float s12, float s21, float s22) {
-  constexpr int TR = 64 / TC, WH = 2 * TR + 2, WSZ = WH * wino_wwp(TC);
-  f32x4 a4[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) a4[i] = *reinterpret_cast<const f32x4*>(ul + i * 32 * CK);
-#pragma unroll
-  for (int q = 0; q < CK / 2; ++q) {
-    const float* prow = patch + (2 * q + lh) * WSZ;
-    float bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float* pp = prow + tbase[j];
-      float v = pp[o11];
-      v = fmaf(s12, pp[o12], v);
-      v = fmaf(s21, pp[o21], v);
-      v = fmaf(s22, pp[o22], v);
-      bv[j] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][q], bv[j], acc[i][j], 0, 0, 0);
-  }
+// value of the horizontally adjacent lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float wino_swap_adjacent(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-template <int MT, int TC, int CK, int ACT, int RES, int EC, int NSTG>
-__device__ __forceinline__ void wino_body(const WinoArgs& a) {
-  constexpr int NT = 2, BM = MT * 32, TR = 64 / TC;
-  // Window rows are stored DE-INTERLEAVED ([even columns | odd columns], padded to WWP) so that the
-  // stride-2 column pattern of neighbouring tiles becomes unit-stride, and WWP is chosen so that the
-  // tile rows of a 32-lane group land on disjoint banks: B-operand reads are bank-conflict free.
-  constexpr int WH = 2 * TR + 2, WW = 2 * TC + 2, WWP = wino_wwp(TC), WSZ = WH * WWP;
-  // U rows are 8 floats = the chunk's channels in the order [0,2,4,6 | 1,3,5,7] (host packing): lane half
-  // lh fetches its four k-steps with ONE ds_read_b128, and the rows are staged by 16-byte LDS-DMA
-  static_assert(CK == 8, "U row layout assumes 8 channels per chunk");
-  constexpr int P_TOT = CK * WSZ, U_TOT4 = 16 * BM * CK / 4;             // U in float4 slots
-  constexpr int P_PER = (P_TOT + 1023) / 1024, U_PER = (U_TOT4 + 1023) / 1024;
-  constexpr int STAGE = P_PER * 1024 + U_PER * 4096;
-  constexpr int MLD = 65, M_TOT = 16 * EC * MLD;    // EC = output channels per epilogue pass (32 or 16)
-  // NSTG = LDS-DMA ring depth: 3 = two chunks in flight behind the one in use, 2 = one
-  constexpr int LDS_F = (NSTG * STAGE > M_TOT ? NSTG * STAGE : M_TOT);
-  __shared__ __attribute__((aligned(16))) float lds[LDS_F + BM];
-  float* const sbias = lds + LDS_F;
+template <int TC, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
+  constexpr int BM = 32, CK = 8, TR = 64 / TC;
+  constexpr int WH = 2 * TR + 2, WW = 2 * TC + 2, NE = WW / 2, WWP = wino_wwp(TC);
+  constexpr int WSZ = WH * WWP, WSZP = wino_pad16(WSZ), ROUNDS = (WSZP + 255) / 256;
+  constexpr int LDU = 20, U_F = CK * BM * LDU, U_PER = U_F / 4 / 256;
+  static_assert(U_F % 1024 == 0, "U stage must be a whole number of 256 x 16-byte slots");
+  constexpr int STAGE = CK * WSZP + U_F;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
-  int pt, ct;
-  xcd_remap(blockIdx.x, a.n_ct, pt, ct);
-  if (pt >= a.n_pt) return;
+  // PERSISTENT work-groups: gridDim.x = 2 x CUs; logical ids are consecutive inside an XCD, and a work-group
+  // walks the items id, id + G, id + 2G ... (item = (pixel block, 32-channel group), channel group fastest: the
+  // groups of one pixel block run side by side on one XCD and share the window in its L2).  The (item, chunk)
+  // pairs form ONE continuous stream through the 2-stage LDS ring: chunk 0 of the next item is in flight while
+  // the last chunk and the register epilogue of the current one run.
+  const int G = gridDim.x;
+  const int wg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int n_items = a.n_pt * a.n_ct;
+  if (wg >= n_items) return;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = Winograd position p
-  const int l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, tl = lane & 15;
   const int H = a.H, W = a.W, HW = H * W;
   const int blks = a.blk_r * a.blk_c;
-  const int b = pt / blks;
-  const int br = (pt - b * blks) / a.blk_c, bc = (pt - b * blks) % a.blk_c;
-  const int oy0 = 2 * br * TR, ox0 = 2 * bc * TC;                  // output origin of the block
-  const float* xb = a.x + (long)b * a.x_bs;
-  if (tid < BM) sbias[tid] = a.bias[ct * BM + tid];
+  const int t = wave * 16 + tl;                      // this lane's tile inside the 64-tile block
+  const int trow = t / TC, tcol = t % TC;
+  const int tbase = (2 * trow) * WWP + tcol;
+  const int poffl = tbase + g * WSZP, uoffl = CK * WSZP + (g * BM + tl) * LDU;
 
-  // ---- LDS-DMA staging: per-slot source offsets are chunk-invariant (-1 = reads as zero) ------------
-  int poff[P_PER], uoff[U_PER];
+  // ---- LDS-DMA staging through buffer loads: per-slot byte offsets are chunk- and channel-invariant VGPRs,
+  // the channel / chunk advance is a scalar offset, and out-of-image slots carry an out-of-range offset that
+  // the buffer bounds check turns into zeros: no vector instruction is spent on addressing inside the loop.
+  unsigned poff[ROUNDS], uoff[U_PER];
+  int slot_r[ROUNDS], slot_c[ROUNDS];                // item-invariant window coordinates of this thread's slots
 #pragma unroll
-  for (int t = 0; t < P_PER; ++t) {
-    const int e = tid + t * 1024;
-    const int ch = e / WSZ, r = e - ch * WSZ;
-    const int sx = r % WWP;                        // slot in the de-interleaved row
-    const int col = sx < WW / 2 ? 2 * sx : 2 * (sx - WW / 2) + 1;
-    const int gy = oy0 - 1 + r / WWP, gx = ox0 - 1 + col;
-    const bool ok = e < P_TOT && sx < WW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    poff[t] = ok ? ch * HW + gy * W + gx : -1;
+  for (int q = 0; q < ROUNDS; ++q) {
+    // the last round is shifted back to end exactly at WSZP (it re-writes a few slots of the previous round
+    // with identical data): every DMA runs with all 256 lanes, no divergent control flow around M0
+    const int e = tid + (q < ROUNDS - 1 ? q * 256 : WSZP - 256);
+    const int r = e / WWP, sx = e - r * WWP;
+    const bool ok = e < WSZ && sx < WW;
+    slot_r[q] = ok ? r - 1 : -0x10000;
+    slot_c[q] = (sx < NE ? 2 * sx : 2 * (sx - NE) + 1) - 1;
   }
+  int uslot[U_PER];
 #pragma unroll
-  for (int t = 0; t < U_PER; ++t) {
-    const int e = tid + t * 1024;                  // float4 slot: row = e/2 = p*BM + co, half = e&1
-    const int row = e >> 1, p = row / BM, co = row - p * BM;
-    uoff[t] = e < U_TOT4 ? (p * a.Cout_pad + ct * BM + co) * CK + (e & 1) * 4 : 0;
+  for (int q = 0; q < U_PER; ++q) {
+    const int e = tid + q * 256;                     // 16-byte slot: channel c = e / (BM*5), then (co, quarter)
+    const int c = e / (BM * 5), rem = e - c * (BM * 5);
+    uslot[q] = (c * a.Cout_pad * LDU + rem * 4) * 4;
   }
-  auto stage = [&](int kc, int st) {
-    float* dst = lds + st * STAGE + wave * 64;
-    const float* xc = xb + (long)kc * CK * HW;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t xrs;
+  const __amdgpu_buffer_rsrc_t urs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), (short)0, a.Cin * a.Cout_pad * LDU * 4, 0x00020000);
+#endif
+  // per-item staging parameters (scalar item -> image, block origin, channel group)
+  auto setup = [&](int item) {
+    const int pt = item / a.n_ct, ct = item - pt * a.n_ct;
+    const int b = pt / blks, rem = pt - b * blks;
+    const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
+    const int oy0 = 2 * br * TR, ox0 = 2 * bc * TC;
 #pragma unroll
-    for (int t = 0; t < P_PER; ++t)
-      __builtin_amdgcn_global_load_lds(poff[t] >= 0 ? xc + poff[t] : &sgta_wino_zero, dst + t * 1024, 4, 0, 0);
-    const float* uc = a.u + (long)kc * 16 * a.Cout_pad * CK;
-    float* udst4 = lds + st * STAGE + P_PER * 1024 + wave * 256;
+    for (int q = 0; q < ROUNDS; ++q) {
+      const int gy = oy0 + slot_r[q], gx = ox0 + slot_c[q];
+      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      poff[q] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+    }
 #pragma unroll
-    for (int t = 0; t < U_PER; ++t)
-      if (U_TOT4 % 1024 == 0 || tid + t * 1024 < U_TOT4)
-        glds16(uc + uoff[t], udst4 + t * 4096);
+    for (int q = 0; q < U_PER; ++q) uoff[q] = (unsigned)(uslot[q] + ct * BM * LDU * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.x_bs), (short)0, a.Cin * HW * 4,
+                                            0x00020000);
+#endif
   };
-  stage(0, 0);
-  if (NSTG == 3 && a.nchunks > 1) stage(1, 1);
+  // one chunk = three DMA batches (window channels 0-3, window channels 4-7, U) so that the issue can be
+  // spread between the MFMA groups of the previous chunk instead of one 21-instruction burst behind the barrier
+  auto stage = [&](int kc, int st, int part) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (part < 2) {
+      float* dst = lds + st * STAGE + wave * 64;
+#pragma unroll
+      for (int c = part * (CK / 2); c < (part + 1) * (CK / 2); ++c)
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + c * WSZP + (q < ROUNDS - 1 ? q * 256 : WSZP - 256)),
+                                                   4, poff[q], (kc * CK + c) * HW * 4, 0, 0);
+    } else {
+      float* udst = lds + st * STAGE + CK * WSZP + wave * 256;
+#pragma unroll
+      for (int q = 0; q < U_PER; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + q * 1024), 16, uoff[q],
+                                                 kc * CK * a.Cout_pad * LDU * 4, 0, 0);
+    }
+#endif
+  };
 
-  const int xi = wave >> 2, nu = wave & 3;          // this wave's Winograd position
-  const int i1 = xi == 0 ? 0 : (xi == 2 ? 2 : 1), i2 = xi == 0 ? 2 : (xi == 1 ? 2 : (xi == 2 ? 1 : 3));
-  const int j1 = nu == 0 ? 0 : (nu == 2 ? 2 : 1), j2 = nu == 0 ? 2 : (nu == 1 ? 2 : (nu == 2 ? 1 : 3));
-  const float si2 = xi == 1 ? 1.0f : -1.0f, sj2 = nu == 1 ? 1.0f : -1.0f;     // first entries are +1
-  const int c1 = (j1 & 1) * (WW / 2) + (j1 >> 1), c2 = (j2 & 1) * (WW / 2) + (j2 >> 1);
-  const int o11 = i1 * WWP + c1, o12 = i1 * WWP + c2, o21 = i2 * WWP + c1, o22 = i2 * WWP + c2;
-  const float s12 = sj2, s21 = si2, s22 = si2 * sj2;
-  int tbase[NT];
+  f32x4 acc[16][2];
+  // operand registers, software-pipelined by hand: positions 0..7 use uA, 8..15 use uB; d = raw 4x4 window
+  f32x4 uA[2][2], uB[2][2];
+  float d[4][4], V[16];
+  auto load_d = [&](const float* prow) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int t = j * 32 + l31;
-    tbase[j] = (2 * (t / TC)) * WWP + (t % TC);
-  }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[r][j] = prow[r * WWP + (j & 1) * NE + (j >> 1)];
+  };
+  auto load_u = [&](f32x4 (&u)[2][2], const float* urow, int half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) u[i][v] = *reinterpret_cast<const f32x4*>(urow + i * 16 * LDU + (half * 2 + v) * 4);
+  };
+  // V = B^T d B :  rows then columns (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+  auto transform = [&]() {
+    float tr[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tr[0][j] = d[0][j] - d[2][j];
+      tr[1][j] = d[1][j] + d[2][j];
+      tr[2][j] = d[2][j] - d[1][j];
+      tr[3][j] = d[1][j] - d[3][j];
+    }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      V[xi * 4 + 0] = tr[xi][0] - tr[xi][2];
+      V[xi * 4 + 1] = tr[xi][1] + tr[xi][2];
+      V[xi * 4 + 2] = tr[xi][2] - tr[xi][1];
+      V[xi * 4 + 3] = tr[xi][1] - tr[xi][3];
+    }
+  };
+  auto mfma8 = [&](const f32x4 (&u)[2][2], int half) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[half * 8 + q][i] =
+            __builtin_amdgcn_mfma_f32_16x16x4f32(u[i][q >> 2][q & 3], V[half * 8 + q], acc[half * 8 + q][i], 0, 0, 0);
+  };
 
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // counted waits + raw barriers: __syncthreads() would drain every LDS-DMA in flight (vmcnt(0))
-  constexpr int G = P_PER + U_PER;                 // LDS-DMA instructions per wave and stage
-  if (NSTG == 3 && a.nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): sbias store
+  int item = wg, sidx = 0;
+  setup(item);
+  stage(0, 0, 0); stage(0, 0, 1); stage(0, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  load_d(lds + poffl);
+  load_u(uA, lds + uoffl, 0);
 
-  int st = 0;
-  for (int kc = 0; kc < a.nchunks; ++kc) {
-    const bool issue = kc + (NSTG - 1) < a.nchunks;
-    if (issue) stage(kc + NSTG - 1, NSTG == 3 ? (st >= 1 ? st - 1 : 2) : (st ^ 1));   // (st + NSTG - 1) % NSTG
-    const float* patch = lds + st * STAGE;
-    wino_chunk<MT, NT, TC, CK, P_PER>(acc, patch, patch + P_PER * 1024 + (wave * BM + l31) * CK + lh * 4, tbase, lh,
-                                      o11, o12, o21, o22, s12, s21, s22);
-    // chunk kc+1 must have landed; chunk kc+2 (just issued) may stay in flight
-    if (NSTG == 3 && issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    st = st == NSTG - 1 ? 0 : st + 1;
-  }
+  while (true) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ct = item % a.n_ct;
+    f32x4 bsv[2];                                     // bias of this lane's 8 output channels (i*16 + 4g + r)
+    bool more = true;
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+      const bool last = kc + 1 >= a.nchunks;
+      int nkc = kc + 1;
+      if (last) {
+        // last chunk of the item: its staging registers are free -> point them at the next item and put that
+        // item's first chunk in flight; fetch the bias for the epilogue
+        more = item + G < n_items;
+        nkc = 0;
+        if (more) setup(item + G);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bsv[i] = *reinterpret_cast<const f32x4*>(a.bias + ct * BM + i * 16 + 4 * g);
+      }
+      const bool dma = more;
+      if (dma) stage(nkc, sidx ^ 1, 0);
+      const float* P0 = lds + sidx * STAGE + poffl;
+      const float* U0 = lds + sidx * STAGE + uoffl;
+      // ---- k-step 0 (channels g of the chunk) ----
+      load_u(uB, U0, 1);
+      transform();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uA, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma) stage(nkc, sidx ^ 1, 1);
+      load_d(P0 + 4 * WSZP);                                // k-step 1 operands fly under the next 16 MFMAs
+      load_u(uA, U0 + 4 * BM * LDU, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (dma) stage(nkc, sidx ^ 1, 2);
+      // ---- k-step 1 (channels 4 + g) ----
+      load_u(uB, U0 + 4 * BM * LDU, 1);
+      transform();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uA, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // every LDS read of this stage has returned; the next chunk has landed once all waves pass the barrier
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      sidx ^= 1;
+      if (more) {                                           // first operands of the next chunk (or next item)
+        load_d(lds + sidx * STAGE + poffl);
+        load_u(uA, lds + sidx * STAGE + uoffl, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(uB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
-  // ---- output transform through LDS: Mbuf[p][co_local 0..31][tile 0..63] ---------------------------
-  float* Mbuf = lds;
-  constexpr int RPP = EC / 2;                      // accumulator registers per 32-row tile and pass
+    // ---- output transform in registers: lane = tile t, output channels i*16 + 4g + r -----------------------
+    {
+      const int pt = item / a.n_ct;
+      const int b = pt / blks, rem = pt - b * blks;
+      const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
+      const int oy = 2 * br * TR + 2 * trow, ox = 2 * bc * TC + 2 * tcol;
+      if (a.vec == 4) {
+        // 16-byte stores: the lanes of two horizontally adjacent tiles trade halves, the even one stores the
+        // four pixels of the upper row, the odd one those of the lower row (W % 4 == 0: a pair is inside the
+        // image or outside it together)
+        const bool odd = tl & 1;
+        const int row = odd ? oy + 1 : oy, col = odd ? ox - 2 : ox;
+        const bool ok = oy < H && ox < W && row < H;
 #pragma unroll
-  for (int e = 0; e < BM / EC; ++e) {
-    const int i = (e * EC) / 32, r0 = ((e * EC) % 32) / 2;     // MFMA row tile and first register of the pass
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+          for (int r = 0; r < 4; ++r) {
+            const int co = ct * BM + i * 16 + 4 * g + r;
+            if (co >= a.Cout) continue;
+            float ra[4], rb[4];
 #pragma unroll
-      for (int r = 0; r < RPP; ++r) {
-        const int rr = r0 + r;
-        const int col = (rr & 3) + 8 * ((rr >> 2) - (r0 >> 2)) + 4 * lh;       // row inside this pass
-        Mbuf[(wave * EC + col) * MLD + j * 32 + l31] = acc[i][j][rr];
-      }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
+            for (int xi = 0; xi < 4; ++xi) {
+              ra[xi] = (acc[xi * 4 + 0][i][r] + acc[xi * 4 + 1][i][r]) + acc[xi * 4 + 2][i][r];
+              rb[xi] = (acc[xi * 4 + 1][i][r] - acc[xi * 4 + 2][i][r]) - acc[xi * 4 + 3][i][r];
+            }
+            const float bs = bsv[i][r];
+            const float v0 = (ra[0] + ra[1]) + ra[2] + bs, v1 = (rb[0] + rb[1]) + rb[2] + bs;
+            const float v2 = (ra[1] - ra[2]) - ra[3] + bs, v3 = (rb[1] - rb[2]) - rb[3] + bs;
+            const float g0 = wino_swap_adjacent(odd ? v0 : v2), g1 = wino_swap_adjacent(odd ? v1 : v3);
+            f32x4 o4 = odd ? f32x4{g0, g1, v2, v3} : f32x4{v0, v1, g0, g1};
+            if (!ok) continue;
+            const long o = (long)co * HW + row * W + col;
+            f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+            if (RES) rr = *reinterpret_cast<const f32x4*>(a.res + (long)b * a.res_bs + o);
 #pragma unroll
-    for (int k = 0; k < EC * 64 / 1024; ++k) {
-      const int item = tid + k * 1024;
-      const int t = item & 63, col = item >> 6;
-      const int co = ct * BM + e * EC + col;
-      float m[4][4];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = Mbuf[(p * EC + col) * MLD + t];
-      float ra[4], rb[4];                          // A^T applied along nu
-#pragma unroll
-      for (int x4 = 0; x4 < 4; ++x4) {
-        ra[x4] = (m[x4][0] + m[x4][1]) + m[x4][2];
-        rb[x4] = (m[x4][1] - m[x4][2]) - m[x4][3];
-      }
-      float y00 = (ra[0] + ra[1]) + ra[2], y01 = (rb[0] + rb[1]) + rb[2];
-      float y10 = (ra[1] - ra[2]) - ra[3], y11 = (rb[1] - rb[2]) - rb[3];
-      const int oy = oy0 + 2 * (t / TC), ox = ox0 + 2 * (t % TC);
-      if (co < a.Cout && oy < H && ox < W) {
-        const float bsv = sbias[e * EC + col];
-        float* yp = a.y + (long)b * a.y_bs + (long)co * HW + oy * W + ox;
-        const float* rp = RES ? a.res + (long)b * a.res_bs + (long)co * HW + oy * W + ox : nullptr;
+            for (int q = 0; q < 4; ++q) {
+              if (RES == 1) o4[q] += rr[q];
+              if (ACT == 1) o4[q] = fmaxf(o4[q], 0.0f);
+              if (ACT == 2) o4[q] = sigmoidf_(o4[q]);
+              if (RES == 2) o4[q] += rr[q];
+            }
+            *reinterpret_cast<f32x4*>(a.y + (long)b * a.y_bs + o) = o4;
+          }
+      } else if (oy < H && ox < W) {
         const bool x1 = ox + 1 < W, y1 = oy + 1 < H;
-        float v[4] = {y00 + bsv, y01 + bsv, y10 + bsv, y11 + bsv};
-        float rr4[4] = {0, 0, 0, 0};
-        if (RES) {
-          rr4[0] = rp[0];
-          if (x1) rr4[1] = rp[1];
-          if (y1) rr4[2] = rp[W];
-          if (x1 && y1) rr4[3] = rp[W + 1];
-        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (RES == 1) v[q] += rr4[q];
-          if (ACT == 1) v[q] = fmaxf(v[q], 0.0f);
-          if (ACT == 2) v[q] = sigmoidf_(v[q]);
-          if (RES == 2) v[q] += rr4[q];
-        }
-        yp[0] = v[0];
-        if (x1) yp[1] = v[1];
-        if (y1) yp[W] = v[2];
-        if (x1 && y1) yp[W + 1] = v[3];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = ct * BM + i * 16 + 4 * g + r;
+            if (co >= a.Cout) continue;
+            float ra[4], rb[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+              ra[xi] = (acc[xi * 4 + 0][i][r] + acc[xi * 4 + 1][i][r]) + acc[xi * 4 + 2][i][r];
+              rb[xi] = (acc[xi * 4 + 1][i][r] - acc[xi * 4 + 2][i][r]) - acc[xi * 4 + 3][i][r];
+            }
+            const float bs = bsv[i][r];
+            float v[4] = {(ra[0] + ra[1]) + ra[2] + bs, (rb[0] + rb[1]) + rb[2] + bs,
+                          (ra[1] - ra[2]) - ra[3] + bs, (rb[1] - rb[2]) - rb[3] + bs};
+            const long o = (long)co * HW + oy * W + ox;
+            float* yp = a.y + (long)b * a.y_bs + o;
+            float rr4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (RES) {
+              const float* rp = a.res + (long)b * a.res_bs + o;
+              if (a.vec == 2) {
+                const float2 q0 = *reinterpret_cast<const float2*>(rp);
+                rr4[0] = q0.x; rr4[1] = q0.y;
+                if (y1) { const float2 q1 = *reinterpret_cast<const float2*>(rp + W); rr4[2] = q1.x; rr4[3] = q1.y; }
+              } else {
+                rr4[0] = rp[0];
+                if (x1) rr4[1] = rp[1];
+                if (y1) rr4[2] = rp[W];
+                if (x1 && y1) rr4[3] = rp[W + 1];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (RES == 1) v[q] += rr4[q];
+              if (ACT == 1) v[q] = fmaxf(v[q], 0.0f);
+              if (ACT == 2) v[q] = sigmoidf_(v[q]);
+              if (RES == 2) v[q] += rr4[q];
+            }
+            if (a.vec == 2) {
+              *reinterpret_cast<float2*>(yp) = float2{v[0], v[1]};
+              if (y1) *reinterpret_cast<float2*>(yp + W) = float2{v[2], v[3]};
+            } else {
+              yp[0] = v[0];
+              if (x1) yp[1] = v[1];
+              if (y1) yp[W] = v[2];
+              if (x1 && y1) yp[W + 1] = v[3];
+            }
+          }
       }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_s_barrier();
+    if (!more) break;
+    item += G;
   }
-}
-
-// 64 output channels per work-group: one 16-wave work-group per CU (<= 128 registers, 3-deep LDS-DMA ring)
-template <int TC, int CK, int ACT, int RES>
-__global__ __launch_bounds__(1024) void conv3x3_wino_kernel(WinoArgs a) {
-  wino_body<2, TC, CK, ACT, RES, 32, 3>(a);
-}
-
-// 32 output channels per work-group, sized (<= 64 registers, <= 80 KB LDS) so that TWO 16-wave work-groups
-// share a CU: one's prologue / output transform overlaps the other's MFMA loop
-template <int TC, int CK, int ACT, int RES>
-__global__ __launch_bounds__(1024, 8) void conv3x3_wino32_kernel(WinoArgs a) {
-  wino_body<1, TC, CK, ACT, RES, 16, 2>(a);
 }
 
 template <int ACT, int RES>
 static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
-  constexpr int CK = 8;
-  auto go = [&](auto kern, int BM, int TC) -> int {
+  auto go = [&](auto kern, int TC) -> int {
     const int TR = 64 / TC;
-    a.n_ct = a.Cout_pad / BM;
+    a.n_ct = a.Cout_pad / 32;
     a.blk_r = cdiv(cdiv(a.H, 2), TR);
     a.blk_c = cdiv(cdiv(a.W, 2), TC);
     a.n_pt = a.B * a.blk_r * a.blk_c;
-    int grid = cdiv(a.n_pt, 8) * 8 * a.n_ct;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, st, a);
+    // persistent: as many work-groups as the device holds at once (2 per CU), never more than items
+    static int resident_by_tile[4] = {0, 0, 0, 0};          // per <ACT, RES> instance and tile shape
+    int& resident = resident_by_tile[tile];
+    if (!resident) {
+      int dev = 0, cus = 0, per_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+        return SGTA_EBADARG;
+      resident = cus * per_cu;
+    }
+    const long items = (long)a.n_pt * a.n_ct;
+    int grid = (int)(items < resident ? items : resident);
+    grid = cdiv(grid, 8) * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   };
-  // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 tile blocks
-  const int mt = tile / 10, tc = tile % 10;
-  if (mt == 2 && a.Cout_pad % 64 == 0) {
-    if (tc == 0) return go(conv3x3_wino_kernel<32, CK, ACT, RES>, 64, 32);
-    if (tc == 1) return go(conv3x3_wino_kernel<16, CK, ACT, RES>, 64, 16);
-    if (tc == 2) return go(conv3x3_wino_kernel<8, CK, ACT, RES>, 64, 8);
-    if (tc == 3) return go(conv3x3_wino_kernel<4, CK, ACT, RES>, 64, 4);
-  }
-  if (mt == 1) {
-    // 32 couts: <= 64 registers and <= 80 KB of LDS, so TWO 16-wave work-groups share a CU and one's
-    // prologue / output transform overlaps the other's MFMA loop
-    if (tc == 0) return go(conv3x3_wino32_kernel<32, CK, ACT, RES>, 32, 32);
-    if (tc == 1) return go(conv3x3_wino32_kernel<16, CK, ACT, RES>, 32, 16);
-    if (tc == 2) return go(conv3x3_wino32_kernel<8, CK, ACT, RES>, 32, 8);
-    if (tc == 3) return go(conv3x3_wino32_kernel<4, CK, ACT, RES>, 32, 4);
+  // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2 output tiles
+  switch (tile) {
+    case 0: return go(conv3x3_wino_kernel<32, ACT, RES>, 32);
+    case 1: return go(conv3x3_wino_kernel<16, ACT, RES>, 16);
+    case 2: return go(conv3x3_wino_kernel<8, ACT, RES>, 8);
+    case 3: return go(conv3x3_wino_kernel<4, ACT, RES>, 4);
   }
   return SGTA_EBADARG;
 }
 
 extern "C" int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float* bias,
-                                     const float* res, long res_bs, float* y, long y_bs, int B, int Cin,
-                                     int H, int W, int Cout, int Cout_pad, int act, int res_mode,
-                                     int tile, hipStream_t st) {
+                                      const float* res, long res_bs, float* y, long y_bs, int B, int Cin,
+                                      int H, int W, int Cout, int Cout_pad, int act, int res_mode, int tile,
+                                      hipStream_t st) {
   if (!x || !u || !bias || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SGTA_EBADARG;
   if (Cin % 8 || Cout_pad % 32 || Cout_pad < Cout) return SGTA_EBADARG;
   if ((res_mode != 0) != (res != nullptr) || (long)Cin * H * W > 0x7fffffffL) return SGTA_EBADARG;
-  if ((long)16 * Cout_pad * 8 > 0x7fffffffL) return SGTA_EBADARG;
+  // buffer descriptors (LDS-DMA with hardware bounds check) address one image / the packed U in 31 bits
+  if ((long)Cin * H * W * 4 > 0x7fffffffL || (long)Cin * Cout_pad * 80 > 0x7fffffffL) return SGTA_EBADARG;
   WinoArgs a{};
   a.x = x; a.x_bs = x_bs; a.u = u; a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 8;
+  // 16- / 8-byte stores and residual loads need widths and plane alignments that are multiples of 4 / 2 pixels
+  auto aligned = [&](int n) {
+    return (W % n == 0) && (y_bs % n == 0) && (((uintptr_t)y & (4 * n - 1)) == 0) &&
+           (!res || ((res_bs % n == 0) && (((uintptr_t)res & (4 * n - 1)) == 0)));
+  };
+  a.vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
   if (act == 1 && res_mode == 0) return launch_wino<1, 0>(a, tile, st);
   if (act == 0 && res_mode == 0) return launch_wino<0, 0>(a, tile, st);
   if (act == 1 && res_mode == 1) return launch_wino<1, 1>(a, tile, st);

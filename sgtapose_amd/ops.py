@@ -129,20 +129,14 @@ class PackedConv:
         if kh == 1 and stride == 1 and co <= 8 and not tap_major:
             self.w_skinny = w.reshape(co, ci).contiguous()
             self.b_skinny = self.bias[:co].contiguous()
-        # Winograd F(2x2,3x3): U = G g G^T, packed [Cin/8][16][Cout_pad][8]
+        # Winograd F(2x2,3x3): U = G g G^T, packed [Cin/8][8][Cout_pad][16 positions + 4 pad]
         self.u_wino = None
         if kh == 3 and stride == 1 and self.pad == 1 and ci % 8 == 0 and not tap_major:
             G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64, device=w.device)
             U = torch.einsum("xi,ocij,yj->ocxy", G, w.double(), G).float()          # [co, ci, 4, 4]
-            up = torch.zeros(ci // 8, 16, self.Cout_pad, 8, dtype=torch.float32, device=w.device)
-            # channel order inside a chunk: even channels then odd ones (one b128 per MFMA lane half)
-            order = torch.tensor([0, 2, 4, 6, 1, 3, 5, 7], device=w.device)
-            up[:, :, :co] = U.reshape(co, ci // 8, 8, 16)[:, :, order].permute(1, 3, 0, 2)
-            self.u_wino = up.contiguous()
-            # register-transform kernel (sgta_conv3x3_winor_f32): [Cin/8][8][Cout_pad][16 positions + 4 pad]
             ur = torch.zeros(ci // 8, 8, self.Cout_pad, 20, dtype=torch.float32, device=w.device)
             ur[:, :, :co, :16] = U.reshape(co, ci // 8, 8, 16).permute(1, 2, 0, 3)
-            self.u_winor = ur.contiguous()
+            self.u_wino = ur.contiguous()
         # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][36][Cout_pad] (k_local = c_local*9 + tap)
         self.wt_dcn8 = None
         if tap_major and kh == 3 and ci % 4 == 0 and self.Cout_pad % 64 == 0:
@@ -175,14 +169,13 @@ class PackedConv:
 
     def wino_tile(self, H, W):
         """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape."""
-        mt = 2 if (self.Cout_pad % 64 == 0 and not WINO_FORCE_MT1) else 1
         ty, tx = -(-H // 2), -(-W // 2)
         best = None
         for code, tc in ((0, 32), (1, 16), (2, 8), (3, 4)):
             tr = 64 // tc
             util = (ty * tx) / float((-(-ty // tr) * tr) * (-(-tx // tc) * tc))
             if best is None or util > best[1] + 1e-9:
-                best = (mt * 10 + code, util)
+                best = (code, util)
         return best[0]
 
     def patch_tile(self, W, tile=0, HW=None):
@@ -266,23 +259,12 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         _lib.call("sgta_conv3x3s2_f32", x.ptr, x.bs, pc.wt_patch.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
                   x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, code, _stream(), meta=meta)
         return out
-    if USE_WINOGRAD and WINO_REG and pc.u_wino is not None and tile == 0:
-        code = pc.wino_tile(x.H, x.W) % 10
-        meta = None
-        if _lib.PROFILE is not None:
-            meta = _conv_meta(pc, out, 2, False)
-            meta["kernel"] = "conv3x3_winor_kernel<%d>" % (32, 16, 8, 4)[code]
-            meta["exec_flops"] = meta["flops"] * 16.0 / 36.0      # F(2x2,3x3): 16 of 36 multiplies
-        _lib.call("sgta_conv3x3_winor_f32", x.ptr, x.bs, pc.u_winor.data_ptr(), pc.bias.data_ptr(), rp, rbs,
-                  out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
-                  res_mode if res is not None else 0, code, _stream(), meta=meta)
-        return out
     if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
         code = pc.wino_tile(x.H, x.W)
         meta = None
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, False)
-            meta["kernel"] = "conv3x3_wino_kernel<%d,%d>" % (code // 10, (32, 16, 8, 4)[code % 10])
+            meta["kernel"] = "conv3x3_wino_kernel<%d>" % (32, 16, 8, 4)[code]
             meta["exec_flops"] = meta["flops"] * 16.0 / 36.0      # F(2x2,3x3): 16 of 36 multiplies
         _lib.call("sgta_conv3x3_wino_f32", x.ptr, x.bs, pc.u_wino.data_ptr(), pc.bias.data_ptr(), rp, rbs,
                   out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
@@ -303,9 +285,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
-WINO_FORCE_MT1 = False         # tools: 32-cout Winograd tiles (two work-groups per CU) everywhere
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
-WINO_REG = True                # Winograd: all-positions-per-wave kernel (False: wave-per-position kernel)
 USE_S2_KERNEL = True           # LDS-window kernel for 3x3 stride-2 convs (False: generic implicit GEMM)
 USE_CONV1X1 = True             # LDS-DMA GEMM kernel for 1x1 convs (False: generic implicit GEMM)
 USE_DCN_LDS_KERNEL = True      # False: gather-from-global DCN (conv_igemm.hip)

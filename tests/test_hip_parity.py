@@ -74,17 +74,16 @@ def test_conv3x3_implementations_agree(ops, cin, cout, H, W):
     pc = ops.PackedConv(w.to(DEV), bias.to(DEV))
     assert pc.u_wino is not None and pc.wt_patch is not None
     out = torch.empty(ref.shape, device=DEV)
-    flags = (ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.WINO_REG)
+    flags = (ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL)
     try:
-        # both Winograd kernels (register-transform, wave-per-position), LDS-range direct, generic implicit GEMM
-        for wino, reg, patch in ((True, True, True), (True, False, True), (False, False, True), (False, False, False)):
-            ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.WINO_REG = wino, patch, reg
+        for wino, patch in ((True, True), (False, True), (False, False)):
+            ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = wino, patch
             out.zero_()
             ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU, res=res.to(DEV), res_mode=1)
             err = float((out.cpu() - ref).abs().max())
-            assert err < (1e-4 if wino else 3e-5), (wino, reg, patch, err)
+            assert err < (1e-4 if wino else 3e-5), (wino, patch, err)
     finally:
-        ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.WINO_REG = flags
+        ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = flags
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(16, 32, 48, 64), (64, 128, 24, 40), (256, 512, 30, 40), (32, 64, 17, 23)])

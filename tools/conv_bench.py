@@ -45,8 +45,6 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--generic", action="store_true", help="force the implicit-GEMM gather kernel")
-    ap.add_argument("--wino-mt1", action="store_true", help="32-cout Winograd tiles")
-    ap.add_argument("--wino-lds", action="store_true", help="wave-per-position Winograd kernel (conv3x3_wino.hip)")
     ap.add_argument("--no-wino", action="store_true", help="direct (LDS-range) 3x3 kernel instead of Winograd")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -54,8 +52,6 @@ def main():
     ops.USE_CONV1X1 = not a.generic
     ops.USE_S2_KERNEL = not a.generic
     ops.USE_WINOGRAD = not (a.generic or a.no_wino)
-    ops.WINO_FORCE_MT1 = a.wino_mt1
-    ops.WINO_REG = not a.wino_lds
     ops.USE_DCN_LDS_KERNEL = not a.generic
     tiles = [int(t) for t in a.tiles.split(",")]
     for name, kind, ci, co, ks, st, H, W, N in SHAPES:

@@ -1,4 +1,4 @@
-// Micro-benchmark: f32 MFMA 16x16x4 issue rate with the operand traffic of conv3x3_winor.hip mixed in
+// Micro-benchmark: f32 MFMA 16x16x4 issue rate with the operand traffic of conv3x3_wino.hip mixed in
 // (GPU box only; not part of the library).  hipcc --offload-arch=gfx950 -O3 tools/mfma16_mix.hip -o /tmp/mix && /tmp/mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
