@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--early-levels", default=None,
+                    help="comma list of pyramid levels whose attention overlaps the backbone on a side stream "
+                         "(engine default: 2,3; empty string: none)")
     ap.add_argument("--skip-dead-levels", action="store_true",
                     help="do not compute temporal levels 0/1 (they never reach the heads); NOT the default")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -126,6 +129,8 @@ def main():
     B, H, W = args.batch, args.height, args.width
     model, sd = build_model(dev)
     model.engine().compute_dead_levels = not args.skip_dead_levels
+    if args.early_levels is not None:
+        model.engine().early_levels = tuple(int(v) for v in args.early_levels.split(",") if v != "")
     det = BatchedDetector(model)
     inp = make_inputs(B, H, W, seed=317 + rank * B)            # this rank's shard of the global batch
     dev_in = [inp[k].to(dev) for k in ARGS]

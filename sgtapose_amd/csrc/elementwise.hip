@@ -34,51 +34,91 @@ extern "C" int sgta_maxpool2_f32(const float* x, long x_bs, float* y, long y_bs,
 }
 
 // ---- y = ConvTranspose2d(C, C, 2f, stride f, pad f/2, groups=C, no bias)(x) + skip ----------------
-// out[oy] gathers the (at most) 2 input rows iy with oy = iy*f - f/2 + ky, 0 <= ky < 2f.
-template <int F, int V>
+// out[oy][ox] gathers the (at most) 2 x 2 inputs (iy, ix) with oy = iy*f - f/2 + ky, 0 <= ky < 2f (same for x).
+// Fast path (Wo % 4 == 0, 16-byte aligned planes): one thread = 4 consecutive output pixels of one (b, c) plane
+// (blockIdx.y): they share 4/f + 2 input columns per row, the kernel-column pattern is a compile-time constant
+// and the two kernel rows are one or two 16-byte loads -- 8 / 6 input loads per 4 outputs instead of 16.
+template <int F>
+__global__ __launch_bounds__(256) void upsample_add4_kernel(const float* __restrict__ x, long x_bs,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ skip, long s_bs,
+                                                            float* __restrict__ y, long y_bs, int C,
+                                                            int H, int W) {
+  constexpr int KS = 2 * F, P = F / 2, NIN = 4 / F + 2;
+  const int Ho = H * F, Wo = W * F, Wq = Wo / 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Ho * Wq) return;
+  const int b = blockIdx.y / C, c = blockIdx.y - b * C;
+  const int oy = idx / Wq, oxq = idx - oy * Wq;
+  const float* xp = x + b * x_bs + (long)c * H * W;
+  const float* wp = w + (long)c * KS * KS;
+  // candidate input rows: iy1 = floor((oy + P) / F) (ky1 in [0,F)), iy0 = iy1 - 1 (ky0 = ky1 + F)
+  const int iy1 = (oy + P) / F, ky1 = oy + P - iy1 * F;
+  const int iy0 = iy1 - 1, ky0 = ky1 + F;
+  const int bx = (4 * oxq) / F - 1;                  // first of the NIN input columns
+  float in0[NIN], in1[NIN], w0[KS], w1[KS];
+  const bool r0 = iy0 >= 0, r1 = iy1 < H;           // iy0 < H and iy1 >= 0 always hold
+#pragma unroll
+  for (int j = 0; j < NIN; ++j) {
+    const int ix = bx + j;
+    const bool cok = ix >= 0 && ix < W;
+    in0[j] = (r0 && cok) ? xp[iy0 * W + ix] : 0.0f;
+    in1[j] = (r1 && cok) ? xp[iy1 * W + ix] : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < KS / 4; ++q) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(wp + ky0 * KS + 4 * q);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(wp + ky1 * KS + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { w0[4 * q + e] = a0[e]; w1[4 * q + e] = a1[e]; }
+  }
+  const long o = ((long)c * Ho + oy) * Wo + oxq * 4;
+  f32x4 out = skip ? *reinterpret_cast<const f32x4*>(skip + b * s_bs + o) : f32x4{0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    constexpr int dummy = 0; (void)dummy;
+    const int j1 = (e + P) / F + 1, j0 = j1 - 1;      // compile-time after unrolling
+    const int kx1 = (e + P) % F, kx0 = kx1 + F;
+    float a = in0[j0] * w0[kx0];
+    a = fmaf(in0[j1], w0[kx1], a);
+    a = fmaf(in1[j0], w1[kx0], a);
+    a = fmaf(in1[j1], w1[kx1], a);
+    out[e] += a;
+  }
+  *reinterpret_cast<f32x4*>(y + b * y_bs + o) = out;
+}
+
+// generic path: one thread = one output pixel
+template <int F>
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float* __restrict__ x, long x_bs,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ skip, long s_bs,
                                                            float* __restrict__ y, long y_bs, int C,
-                                                           int H, int W, long total4) {
-  // one thread = V consecutive output pixels of a row (V = 4: 16-byte skip load / output store)
+                                                           int H, int W, long total) {
   constexpr int KS = 2 * F, P = F / 2;
-  const int Ho = H * F, Wo = W * F, Wq = Wo / V;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    int oxq = (int)(i % Wq);
-    long t = i / Wq;
+  const int Ho = H * F, Wo = W * F;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int ox = (int)(i % Wo);
+    long t = i / Wo;
     int oy = (int)(t % Ho);
     t /= Ho;
     int c = (int)(t % C);
     int b = (int)(t / C);
     const float* xp = x + b * x_bs + (long)c * H * W;
     const float* wp = w + (long)c * KS * KS;
-    // candidate input rows: iy1 = floor((oy + P) / F) (ky1 in [0,F)), iy0 = iy1 - 1 (ky0 = ky1 + F)
     const int iy1 = (oy + P) / F, ky1 = oy + P - iy1 * F;
     const int iy0 = iy1 - 1, ky0 = ky1 + F;
     const bool r0 = iy0 >= 0 && iy0 < H, r1 = iy1 >= 0 && iy1 < H;
-    const long o = ((long)c * Ho + oy) * Wo + oxq * V;
-    float acc[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const int ox = oxq * V + e;
-      const int ix1 = (ox + P) / F, kx1 = ox + P - ix1 * F;
-      const int ix0 = ix1 - 1, kx0 = kx1 + F;
-      const bool c0 = ix0 >= 0 && ix0 < W, c1 = ix1 >= 0 && ix1 < W;
-      float a = 0.0f;
-      if (r0 && c0) a = fmaf(xp[iy0 * W + ix0], wp[ky0 * KS + kx0], a);
-      if (r0 && c1) a = fmaf(xp[iy0 * W + ix1], wp[ky0 * KS + kx1], a);
-      if (r1 && c0) a = fmaf(xp[iy1 * W + ix0], wp[ky1 * KS + kx0], a);
-      if (r1 && c1) a = fmaf(xp[iy1 * W + ix1], wp[ky1 * KS + kx1], a);
-      acc[e] = a;
-    }
-    if (V == 4) {
-      f32x4 out = skip ? *reinterpret_cast<const f32x4*>(skip + b * s_bs + o) : f32x4{0, 0, 0, 0};
-      out += f32x4{acc[0], acc[1], acc[2], acc[3]};
-      *reinterpret_cast<f32x4*>(y + b * y_bs + o) = out;
-    } else {
-      y[b * y_bs + o] = acc[0] + (skip ? skip[b * s_bs + o] : 0.0f);
-    }
+    const int ix1 = (ox + P) / F, kx1 = ox + P - ix1 * F;
+    const int ix0 = ix1 - 1, kx0 = kx1 + F;
+    const bool c0 = ix0 >= 0 && ix0 < W, c1 = ix1 >= 0 && ix1 < W;
+    float a = 0.0f;
+    if (r0 && c0) a = fmaf(xp[iy0 * W + ix0], wp[ky0 * KS + kx0], a);
+    if (r0 && c1) a = fmaf(xp[iy0 * W + ix1], wp[ky0 * KS + kx1], a);
+    if (r1 && c0) a = fmaf(xp[iy1 * W + ix0], wp[ky1 * KS + kx0], a);
+    if (r1 && c1) a = fmaf(xp[iy1 * W + ix1], wp[ky1 * KS + kx1], a);
+    const long o = ((long)c * Ho + oy) * Wo + ox;
+    y[b * y_bs + o] = a + (skip ? skip[b * s_bs + o] : 0.0f);
   }
 }
 
@@ -86,16 +126,19 @@ extern "C" int sgta_upsample_add_f32(const float* x, long x_bs, const float* w, 
                                      long s_bs, float* y, long y_bs, int B, int C, int H, int W,
                                      int f, hipStream_t st) {
   if (!x || !w || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
-  const int v = ((W * f) % 4 == 0 && (x_bs % 4) == 0 && (s_bs % 4) == 0 && (y_bs % 4) == 0) ? 4 : 1;
-  long total = (long)B * C * H * f * W * f / v;
-  int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-#define SGTA_UP(F, V) hipLaunchKernelGGL((upsample_add_kernel<F, V>), dim3(grid), dim3(256), 0, st, x, x_bs, w, skip, s_bs, y, y_bs, C, H, W, total)
-  if (f == 2 && v == 4) SGTA_UP(2, 4);
-  else if (f == 2) SGTA_UP(2, 1);
-  else if (f == 4 && v == 4) SGTA_UP(4, 4);
-  else if (f == 4) SGTA_UP(4, 1);
-  else return SGTA_EBADARG;
-#undef SGTA_UP
+  if (f != 2 && f != 4) return SGTA_EBADARG;
+  const bool v4 = (W * f) % 4 == 0 && (s_bs % 4) == 0 && (y_bs % 4) == 0 && ((uintptr_t)y & 15) == 0 &&
+                  (!skip || ((uintptr_t)skip & 15) == 0) && ((uintptr_t)w & 15) == 0 && (long)B * C <= 65535;
+  if (v4) {
+    const dim3 grid(cdiv(H * f * (W * f / 4), 256), B * C);
+    if (f == 2) hipLaunchKernelGGL(upsample_add4_kernel<2>, grid, dim3(256), 0, st, x, x_bs, w, skip, s_bs, y, y_bs, C, H, W);
+    else hipLaunchKernelGGL(upsample_add4_kernel<4>, grid, dim3(256), 0, st, x, x_bs, w, skip, s_bs, y, y_bs, C, H, W);
+  } else {
+    const long total = (long)B * C * H * f * W * f;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (f == 2) hipLaunchKernelGGL(upsample_add_kernel<2>, dim3(grid), dim3(256), 0, st, x, x_bs, w, skip, s_bs, y, y_bs, C, H, W, total);
+    else hipLaunchKernelGGL(upsample_add_kernel<4>, dim3(grid), dim3(256), 0, st, x, x_bs, w, skip, s_bs, y, y_bs, C, H, W, total);
+  }
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

@@ -39,7 +39,8 @@ class Engine:
         self.ks = list(model.kernel_list)
         self.scales = list(model.scale_list)
         self.num_classes = int(model.opt.num_classes)
-        self.use_side_stream = True          # overlap the (dead-end) level-0/1 attention with the neck / heads
+        self.use_side_stream = True          # side stream: early_levels beside the backbone, levels 0/1 beside the neck
+        self.early_levels = (2, 3)           # levels whose attention (minus write-back) overlaps the deeper backbone
         self.use_c16 = True                  # 16-cout MFMA kernels for the stems / level0 (False: generic conv)
         self.compute_dead_levels = True      # levels 0/1 never reach the heads (dla.py:600-606); the
         #                                      reference still computes them, and so do we by default
@@ -170,8 +171,9 @@ class Engine:
         self._tree_l1(node.tree1, name + ".tree1", x, t1, cat1, bottom=bottom)
         return self._tree_l1(inner, name + ".tree2", t1, out, cat2)
 
-    def backbone(self, x, pre_img, pre_hm, repro_hm):
-        """Both frames as one batch of 2B (previous first).  Returns the six level Views [2B, C_i, ...]."""
+    def backbone(self, x, pre_img, pre_hm, repro_hm, after_level=None):
+        """Both frames as one batch of 2B (previous first).  Returns the six level Views [2B, C_i, ...].
+        ``after_level(i, view)`` is called as soon as level i's kernels are enqueued."""
         B, _, H, W = x.shape
         N = 2 * B
         P = self.P
@@ -189,61 +191,77 @@ class Engine:
             ops.conv_c16(View(s), None, P["level0.c16"], lv[0])
         else:
             ops.conv2d(View(s), P["level0"], lv[0], ACT_RELU)
+        if after_level:
+            after_level(0, lv[0])
         lv.append(self.vbuf("l1", N, 32, H // 2, W // 2))
         ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
+        if after_level:
+            after_level(1, lv[1])
         ch = self.model.base.channels
         for i in range(2, 6):
             out = self.vbuf("l%d" % i, N, ch[i], H >> i, W >> i)
             self._tree(getattr(self.model.base, "level%d" % i), "level%d" % i, lv[i - 1], out)
             lv.append(out)
+            if after_level:
+                after_level(i, out)
         return lv
 
     # ------------------------------------------------------------------------------------------
+    def temporal_tokens(self, feats, i, idx, B):
+        """Temporal stage of pyramid level ``i`` up to (not including) the write-back: reads both frame halves of
+        ``feats`` only, so it may run beside the deeper backbone levels.  -> (z, fid, win) for temporal_scatter."""
+        K = self.num_classes
+        C, H, W = feats.C, feats.H, feats.W
+        pre_f, cur_f = View(feats.base[:B]), View(feats.base[B:])
+        n = K * (1 + 2 * (self.ks[i] // 2)) ** 2
+        fid, win = ops.window_index(idx, float(self.scales[i]), self.ks[i], H, W,
+                                    self.buf("fid%d" % i, (2, B, n), torch.int64),
+                                    self.buf("win%d" % i, (B, n), torch.uint8))
+        M = B * n
+        cat_tok = self.buf("cat_tok%d" % i, (M, 2 * C))
+        ops.window_gather(cur_f, fid[1], cat_tok, col0=C)
+        if i <= 2:
+            T = self.tf[i]
+            hid = T["hid"]
+            key = self.buf("key%d" % i, (M, C))
+            cur = self.buf("qry%d" % i, (M, C))
+            ops.window_gather(pre_f, fid[0], key)
+            ops.window_gather(cur_f, fid[1], cur)
+            kv = ops.linear(key, T["wkv"], None, self.buf("kv%d" % i, (M, 2 * hid)))
+            q = self.buf("q%d" % i, (M, hid))
+            att = self.buf("att%d" % i, (M, hid))
+            y1 = self.buf("y1_%d" % i, (M, C))
+            hdn = self.buf("ffn%d" % i, (M, D_FFN))
+            nxt = self.buf("qry_b%d" % i, (M, C))
+            for it in range(3):                    # ONE shared layer, three times (dla.py:788-803)
+                ops.linear(cur, T["wq"], None, q)
+                ops.mhca(q, kv[:, :hid], kv[:, hid:], T["pos"], att, B, n, N_HEADS, hid // N_HEADS)
+                ops.linear(att, T["fc_w"], T["fc_b"], y1, res=cur, ln=T["ln1"])
+                ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
+                dst = cat_tok[:, :C] if it == 2 else nxt
+                ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
+                cur, nxt = dst, cur
+        else:
+            ops.window_gather(pre_f, fid[0], cat_tok, col0=0)
+        Cc = self.cat[i]
+        h1 = ops.linear(cat_tok, Cc["w0"], Cc["b0"], self.buf("cat_h%d" % i, (M, 4 * C)), relu=True)
+        z = ops.linear(h1, Cc["w2"], Cc["b2"], self.buf("cat_z%d" % i, (M, C)))
+        return z, fid, win
+
+    def temporal_scatter(self, feats, B, tok):
+        """Write the substituted tokens into the current-frame half of ``feats`` (in place, last-wins)."""
+        z, fid, win = tok
+        ops.window_scatter(z, fid[1], win, View(feats.base[B:]))
+
     def temporal(self, lv, idx, B, levels):
         """In-place temporal stage on the current-frame halves of ``lv`` for the given pyramid levels;
         ``idx`` = prior arg-max coordinates.  Returns the level-0 window ids (or None)."""
-        K = self.num_classes
         fid0 = None
         for i in levels:
-            feats = lv[i]
-            C, H, W = feats.C, feats.H, feats.W
-            pre_f, cur_f = View(feats.base[:B]), View(feats.base[B:])
-            n = K * (1 + 2 * (self.ks[i] // 2)) ** 2
-            fid, win = ops.window_index(idx, float(self.scales[i]), self.ks[i], H, W,
-                                        self.buf("fid%d" % i, (2, B, n), torch.int64),
-                                        self.buf("win%d" % i, (B, n), torch.uint8))
+            tok = self.temporal_tokens(lv[i], i, idx, B)
+            self.temporal_scatter(lv[i], B, tok)
             if i == 0:
-                fid0 = fid
-            M = B * n
-            cat_tok = self.buf("cat_tok%d" % i, (M, 2 * C))
-            ops.window_gather(cur_f, fid[1], cat_tok, col0=C)
-            if i <= 2:
-                T = self.tf[i]
-                hid = T["hid"]
-                key = self.buf("key%d" % i, (M, C))
-                cur = self.buf("qry%d" % i, (M, C))
-                ops.window_gather(pre_f, fid[0], key)
-                ops.window_gather(cur_f, fid[1], cur)
-                kv = ops.linear(key, T["wkv"], None, self.buf("kv%d" % i, (M, 2 * hid)))
-                q = self.buf("q%d" % i, (M, hid))
-                att = self.buf("att%d" % i, (M, hid))
-                y1 = self.buf("y1_%d" % i, (M, C))
-                hdn = self.buf("ffn%d" % i, (M, D_FFN))
-                nxt = self.buf("qry_b%d" % i, (M, C))
-                for it in range(3):                    # ONE shared layer, three times (dla.py:788-803)
-                    ops.linear(cur, T["wq"], None, q)
-                    ops.mhca(q, kv[:, :hid], kv[:, hid:], T["pos"], att, B, n, N_HEADS, hid // N_HEADS)
-                    ops.linear(att, T["fc_w"], T["fc_b"], y1, res=cur, ln=T["ln1"])
-                    ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
-                    dst = cat_tok[:, :C] if it == 2 else nxt
-                    ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
-                    cur, nxt = dst, cur
-            else:
-                ops.window_gather(pre_f, fid[0], cat_tok, col0=0)
-            Cc = self.cat[i]
-            h1 = ops.linear(cat_tok, Cc["w0"], Cc["b0"], self.buf("cat_h%d" % i, (M, 4 * C)), relu=True)
-            z = ops.linear(h1, Cc["w2"], Cc["b2"], self.buf("cat_z%d" % i, (M, C)))
-            ops.window_scatter(z, fid[1], win, cur_f)
+                fid0 = tok[1]
         return fid0
 
     # ------------------------------------------------------------------------------------------
@@ -304,28 +322,49 @@ class Engine:
         if tuple(pre_hm_cls.shape) != (B, self.num_classes, H // 4, W // 4):
             raise ValueError("pre_hm_cls must be [B,%d,H/4,W/4]" % self.num_classes)
         with torch.no_grad():
-            lv = self.backbone(x, pre_img, pre_hm, repro_hm)
             idx = ops.prior_argmax(pre_hm_cls, repro_hm_cls, self.buf("idx", (2, B, self.num_classes, 2)))
-            # Levels 0 and 1 never reach the heads (dla_up starts at level 2, dla.py:600-606): their
-            # attention (the largest token counts, latency-bound kernels) runs on a side stream beside the
-            # MFMA-bound neck / heads; levels 2-5 feed the neck and stay on the main stream.
+            # The attention of a level only READS that level's features until its final write-back, and it is a
+            # chain of small latency-bound kernels.  ``early_levels`` run on a side stream as soon as their
+            # features exist, beside the MFMA-bound deeper backbone levels; their write-backs follow on the main
+            # stream once the backbone no longer reads the features.  Levels 0/1 never reach the heads (dla_up
+            # starts at level 2, dla.py:600-606; the reference still computes them, and so do we unless
+            # compute_dead_levels is off): by default their whole stage runs beside the neck / heads instead.
             main = torch.cuda.current_stream()
-            side = None
+            side = self._side_stream() if (self.use_side_stream and _lib.PROFILE is None) else None
+            early = self.early_levels if side is not None else ()
+            tok = {}
+
+            def after_level(i, feats):
+                if i in early:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        tok[i] = self.temporal_tokens(feats, i, idx, B)
+
+            lv = self.backbone(x, pre_img, pre_hm, repro_hm, after_level)
+            if early:
+                main.wait_stream(side)
             self.last_fid0 = None
+            dead_on_side = False
             if self.compute_dead_levels:
-                if self.use_side_stream and _lib.PROFILE is None:
-                    side = self._side_stream()
+                if side is not None and 0 not in early and 1 not in early:
+                    # levels 0/1 are never read again: their whole stage runs beside the neck / heads
+                    dead_on_side = True
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         self.last_fid0 = self.temporal(lv, idx, B, (0, 1))
                 else:
-                    self.last_fid0 = self.temporal(lv, idx, B, (0, 1))
-            self.temporal(lv, idx, B, (2, 3, 4, 5))
+                    for i in (0, 1):
+                        t01 = tok.get(i) or self.temporal_tokens(lv[i], i, idx, B)
+                        self.temporal_scatter(lv[i], B, t01)
+                        if i == 0:
+                            self.last_fid0 = t01[1]
+            for i in (2, 3, 4, 5):
+                self.temporal_scatter(lv[i], B, tok.get(i) or self.temporal_tokens(lv[i], i, idx, B))
             cur = [View(v.base[B:]) for v in lv]
             feat = self.neck(cur)
             self.last_feat = feat
             out = self.heads(feat, hm_act, static)
-            if side is not None:
+            if dead_on_side:
                 main.wait_stream(side)             # the step is complete only when the side work is
             return out
 

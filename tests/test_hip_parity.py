@@ -207,12 +207,14 @@ def test_maxpool_and_upsample_add(ops):
     ops.maxpool2(x.to(DEV), out)
     assert torch.equal(out.cpu(), F.max_pool2d(x, 2, 2))
     for f in (2, 4):
-        w = torch.rand(24, 1, 2 * f, 2 * f, generator=g)
-        skip = torch.randn(2, 24, 12 * f, 20 * f, generator=g)
-        ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=24) + skip
-        o = torch.empty(ref.shape, device=DEV)
-        ops.upsample_add(x.to(DEV), w.to(DEV), skip.to(DEV), o, f)
-        assert torch.allclose(o.cpu(), ref, atol=1e-5, rtol=1e-5)
+        for (h, w_) in ((12, 20), (7, 5), (3, 3), (1, 2)):          # 4-pixel fast path and the generic one
+            xs = torch.randn(2, 24, h, w_, generator=g)
+            w = torch.rand(24, 1, 2 * f, 2 * f, generator=g)
+            skip = torch.randn(2, 24, h * f, w_ * f, generator=g)
+            ref = F.conv_transpose2d(xs, w, None, stride=f, padding=f // 2, groups=24) + skip
+            o = torch.empty(ref.shape, device=DEV)
+            ops.upsample_add(xs.to(DEV), w.to(DEV), skip.to(DEV), o, f)
+            assert torch.allclose(o.cpu(), ref, atol=1e-5, rtol=1e-5), (f, h, w_)
 
 
 # ---------------------------------------------------------------------------------------------
