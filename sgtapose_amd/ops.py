@@ -137,6 +137,16 @@ class PackedConv:
             ur = torch.zeros(ci // 8, 8, self.Cout_pad, 20, dtype=torch.float32, device=w.device)
             ur[:, :, :co, :16] = U.reshape(co, ci // 8, 8, 16).permute(1, 2, 0, 3)
             self.u_wino = ur.contiguous()
+        # Winograd F(4x4,3x3): U = G g G^T (6x6), packed [Cin/4][4][Cout_pad][36]
+        self.u_wino4 = None
+        if kh == 3 and stride == 1 and self.pad == 1 and ci % 4 == 0 and not tap_major:
+            G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                               [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                              dtype=torch.float64, device=w.device)
+            U4 = torch.einsum("xi,ocij,yj->ocxy", G4, w.double(), G4).float()       # [co, ci, 6, 6]
+            u4 = torch.zeros(ci // 4, 4, self.Cout_pad, 36, dtype=torch.float32, device=w.device)
+            u4[:, :, :co] = U4.reshape(co, ci // 4, 4, 36).permute(1, 2, 0, 3)
+            self.u_wino4 = u4.contiguous()
         # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][36][Cout_pad] (k_local = c_local*9 + tap)
         self.wt_dcn8 = None
         if tap_major and kh == 3 and ci % 4 == 0 and self.Cout_pad % 64 == 0:
@@ -166,6 +176,17 @@ class PackedConv:
             if best is None or util > best[1] + 1e-9:
                 best = (mt * 10 + code, util)
         return best[0] if best[1] >= 0.7 else 0          # poorly filled tiles: generic implicit GEMM wins
+
+    def wino4_tile(self, H, W):
+        """(tile code, utilisation) of the best-filling 64-tile block shape for sgta_conv3x3_wino4_f32 (4x4 tiles)."""
+        ty, tx = -(-H // 4), -(-W // 4)
+        best = None
+        for code, tc in ((0, 32), (1, 16), (2, 8), (3, 4)):
+            tr = 64 // tc
+            util = (H * W) / float((-(-ty // tr) * tr) * (-(-tx // tc) * tc) * 16)
+            if best is None or util > best[1] + 1e-9:
+                best = (code, util)
+        return best
 
     def wino_tile(self, H, W):
         """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape."""
@@ -259,6 +280,20 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         _lib.call("sgta_conv3x3s2_f32", x.ptr, x.bs, pc.wt_patch.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
                   x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, code, _stream(), meta=meta)
         return out
+    if (USE_WINOGRAD and USE_WINO4 and pc.u_wino4 is not None and tile == 0 and x.W % 4 == 0 and x.bs % 4 == 0
+            and out.bs % 4 == 0 and x.ptr % 16 == 0 and out.ptr % 16 == 0
+            and (res is None or (rbs % 4 == 0 and rp % 16 == 0))):
+        code, util = pc.wino4_tile(x.H, x.W)
+        if util >= WINO4_MIN_FILL:
+            meta = None
+            if _lib.PROFILE is not None:
+                meta = _conv_meta(pc, out, 2, False)
+                meta["kernel"] = "conv3x3_wino4_kernel<%d>" % (32, 16, 8, 4)[code]
+                meta["exec_flops"] = meta["flops"] * 36.0 / 144.0     # F(4x4,3x3): 36 of 144 multiplies
+            _lib.call("sgta_conv3x3_wino4_f32", x.ptr, x.bs, pc.u_wino4.data_ptr(), pc.bias.data_ptr(), rp, rbs,
+                      out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
+                      res_mode if res is not None else 0, code, _stream(), meta=meta)
+            return out
     if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
         code = pc.wino_tile(x.H, x.W)
         meta = None
@@ -285,6 +320,8 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
+USE_WINO4 = True               # F(4x4,3x3) where the map fills its 64-tile blocks (else F(2x2,3x3))
+WINO4_MIN_FILL = 0.7           # minimum useful fraction of the 4x4-tile blocks
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
 USE_S2_KERNEL = True           # LDS-window kernel for 3x3 stride-2 convs (False: generic implicit GEMM)
 USE_CONV1X1 = True             # LDS-DMA GEMM kernel for 1x1 convs (False: generic implicit GEMM)

@@ -60,7 +60,7 @@ def test_conv2d_bn_relu_residual(ops, cin, cout, ks, stride, tile):
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 24, 40), (128, 27, 15, 20), (16, 96, 17, 23), (64, 768, 8, 12), (512, 512, 15, 20),
-                                          (32, 64, 5, 130), (24, 40, 64, 6)])
+                                          (32, 64, 5, 130), (24, 40, 64, 6), (8, 16, 64, 16), (24, 48, 30, 132), (64, 64, 34, 36)])
 def test_conv3x3_implementations_agree(ops, cin, cout, H, W):
     """Winograd F(2x2,3x3), the LDS-range direct kernel and the generic implicit GEMM against torch,
     incl. odd map sizes (partial 2x2 tiles), residual + ReLU, and a non-multiple-of-32 Cout."""
@@ -74,16 +74,18 @@ def test_conv3x3_implementations_agree(ops, cin, cout, H, W):
     pc = ops.PackedConv(w.to(DEV), bias.to(DEV))
     assert pc.u_wino is not None and pc.wt_patch is not None
     out = torch.empty(ref.shape, device=DEV)
-    flags = (ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL)
+    flags = (ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.USE_WINO4, ops.WINO4_MIN_FILL)
     try:
-        for wino, patch in ((True, True), (False, True), (False, False)):
-            ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = wino, patch
+        ops.WINO4_MIN_FILL = 0.0        # F(4x4,3x3) whenever its alignment contract holds (W % 4 == 0)
+        # F(4x4,3x3) (or F(2x2,3x3) when W % 4 != 0), F(2x2,3x3), LDS-range direct, generic implicit GEMM
+        for wino, w4, patch in ((True, True, True), (True, False, True), (False, False, True), (False, False, False)):
+            ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.USE_WINO4 = wino, patch, w4
             out.zero_()
             ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU, res=res.to(DEV), res_mode=1)
             err = float((out.cpu() - ref).abs().max())
-            assert err < (1e-4 if wino else 3e-5), (wino, patch, err)
+            assert err < (2e-4 if w4 else (1e-4 if wino else 3e-5)), (wino, w4, patch, err)
     finally:
-        ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL = flags
+        ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.USE_WINO4, ops.WINO4_MIN_FILL = flags
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(16, 32, 48, 64), (64, 128, 24, 40), (256, 512, 30, 40), (32, 64, 17, 23)])

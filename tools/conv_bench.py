@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--generic", action="store_true", help="force the implicit-GEMM gather kernel")
+    ap.add_argument("--no-wino4", action="store_true", help="Winograd F(2x2,3x3) everywhere (no F(4x4,3x3))")
     ap.add_argument("--no-wino", action="store_true", help="direct (LDS-range) 3x3 kernel instead of Winograd")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -52,6 +53,7 @@ def main():
     ops.USE_CONV1X1 = not a.generic
     ops.USE_S2_KERNEL = not a.generic
     ops.USE_WINOGRAD = not (a.generic or a.no_wino)
+    ops.USE_WINO4 = not a.no_wino4
     ops.USE_DCN_LDS_KERNEL = not a.generic
     tiles = [int(t) for t in a.tiles.split(",")]
     for name, kind, ci, co, ks, st, H, W, N in SHAPES:
