@@ -65,7 +65,10 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 template <int TC, int ACT, int RES>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
   constexpr int BM = 16, CK = 4, TR = 64 / TC, EDGE = TC < 16 ? TC : 16;
-  constexpr int WH = 4 * TR + 2, WWL = w4_wwl(TC), WQR = WWL / 4, WSZ = WH * WWL, WQ = WSZ / 4;
+  // channel plane stride == 8 (mod 32): the four channels of a wave's edge-lane reads (4-byte, a few lanes) use
+  // different banks
+  constexpr int WH = 4 * TR + 2, WWL = w4_wwl(TC), WQR = WWL / 4;
+  constexpr int WSZ = WH * WWL + ((8 - (WH * WWL) % 32) + 32) % 32, WQ = WSZ / 4;
   constexpr int P_SLOTS = CK * WQ, P_PER = (P_SLOTS + 255) / 256;          // 16-byte window slots per stage
   constexpr int LDU = 36, U_F = CK * BM * LDU, U_SLOTS = U_F / 4, U_PER = (U_SLOTS + 255) / 256;
   static_assert(P_SLOTS >= 256 && U_SLOTS >= 256, "a DMA round must be full");
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
       const int c = e / WQ, rq = e - c * WQ;
       const int r = rq / WQR, qx = rq - r * WQR;
       const int gy = oy0 - 1 + r, gx = ox0 - 4 + 4 * qx;
-      const bool ok = qx < TC + 2 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const bool ok = qx < TC + 2 && r < WH && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       poff[q] = ok ? (unsigned)(c * HW + gy * W + gx) * 4u : 0x80000000u;
     }
 #pragma unroll

@@ -8,8 +8,11 @@ import csv
 import glob
 import sys
 
-NAMES = ["stem_img", "stem_hm", "level0", "level1", "l2_3x3", "l3_3x3", "l4_3x3", "l5_3x3", "l3_root", "heads0",
-         "om_64", "om_128", "dcn_64_64", "dcn_128_64", "dcn_128_128", "dcn_512_256"]
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conv_bench import SHAPES          # noqa: E402  (same order as the launches in the trace)
+
+NAMES = [sh[0] for sh in SHAPES]
 
 
 def load(d):
