@@ -195,8 +195,9 @@ def main():
                               "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F32_MFMA, 4), "traffic": None,
                               "executed": round(exe, 2), "executed_frac": round(exe / PEAK_TFLOPS_F32_MFMA, 4),
                               "note": "achieved = algorithmic (direct-conv, un-padded) FLOPs / measured kernel time; "
-                                      "Winograd F(2x2,3x3) kernels execute 16/36 of them, so achieved may exceed the "
-                                      "f32 MFMA peak while executed_frac is the matrix-pipe utilisation",
+                                      "the Winograd kernels issue only 16/36 (F(2x2,3x3)) or 36/144 (F(4x4,3x3)) of them to "
+                                      "the matrix pipe, so achieved may exceed the f32 MFMA peak while executed_frac is "
+                                      "the matrix-pipe utilisation",
                               "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
                               "share_of_step": round(ta["ms"] / tot, 3)}
         extra = []
