@@ -193,6 +193,30 @@ int sgta_peaks_decode(const float* hm, const float* reg, const float* tracking, 
 int sgta_softargmax(const float* hm, float* out_xy, int B, int K, int H, int W, float beta,
                     float size_mult, sgta_stream_t stream);
 
+/* ---- the steps either side of the network ------------------------------------ */
+
+/* get_prev_hm_wo_noise (per_class = 0: ONE map, key-points max-combined) / get_prev_hm_wo_noise_cls (per_class = 1:
+ * one map per key-point) of sgtapose/utilities.py:1045-1057, 1086-1098, incl. affine_transform_and_clip
+ * (:943-972) and draw_umich_gaussian (:800-821, radius 4, sigma 2, integer centre, skipped at the border).
+ * kps f64 [B,K,2] raw-image coordinates; trans f64 [B,2,3] (meta['trans_input'] / meta['trans_output']);
+ * raw_wh int32 [B,2] = (meta['width'], meta['height']); has_prior u8 [B] (0 = the reference's
+ * ``kp_projs_raw is None``: zero map); table f32 [81] = exp(-(dx^2+dy^2)/8) evaluated in f64 by the caller.
+ * out f32 [B, per_class ? K : 1, Hm, Wm] contiguous; it is zeroed by this call.  Inputs must be finite. */
+int sgta_render_priors(const double* kps, const double* trans, const int* raw_wh, const unsigned char* has_prior,
+                       const float* table, float* out, int B, int K, int Hm, int Wm, int per_class,
+                       sgta_stream_t stream);
+
+/* dream_generic_post_process (sgtapose/lib/utils/post_process.py:93-175) for the keys of this path, and
+ * SGTADetector._get_final_kps (sgtapose/lib/sgta_detector.py:608-651, is_ct path).  Inputs = the device dets of
+ * sgta_peaks_decode (scores f32 [B,K], cts int64 [B,K,2], cts_wreg / regs / tracking f32 [B,K,2]; tracking may be
+ * NULL) and trans_inv f32 [B,2,3] = get_affine_transform(c, s, 0, (w, h), inv=1).astype(float32).
+ * Outputs: valid u8 [B,K] (score >= out_thresh), ct / ct_wreg / reg / trk f32 [B,K,2] in raw-image coordinates,
+ * final_kps f64 [B,K,2] (-999.999*4 where the class has no detection). */
+int sgta_post_process(const float* scores, const long long* cts, const float* cts_wreg, const float* regs,
+                      const float* tracking, const float* trans_inv, float out_thresh, unsigned char* valid,
+                      float* ct, float* ct_wreg, float* reg, float* trk, double* final_kps, int B, int K,
+                      sgta_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,8 @@ Parity status
   imports the reference's own Python files in the build container (with import stubs) and
   stores input/output vectors under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks
   this package against them.
+* ``oracle/prepost.py`` (prior rendering, post-processing) is pinned the same way; only its
+  3-point affine solve stands in for ``cv2.getAffineTransform`` (OpenCV absent: unpinned, see that file).
 * The deformable convolution (DCNv2) lives in an un-vendored third-party dependency of the
   reference (github.com/lbin/DCNv2, branch ``pytorch_1.9``; reference README.md:21-28, import
   site sgtapose/lib/model/networks/dla.py:21-25, only call site dla.py:545-548).  Its source
@@ -26,3 +28,4 @@ from .temporal import (topk_index, window_coords, window_gather, mhca_forward,  
 from .decode import (gaussian_filter_f32, peaks_from_maps, peaks_info, dream_decode,  # noqa: F401
                      soft_argmax_pavlo)
 from .forward import plan_a_window_forward, process_reference          # noqa: F401
+from . import prepost                                                   # noqa: F401  (section 8f rank 1)

@@ -4,7 +4,7 @@ numpy dets, but for B >= 1 frame pairs and entirely on the device until the fina
 """
 import torch
 
-from . import ops
+from . import ops, prepost
 from .decode import dream_generic_decode
 
 
@@ -36,6 +36,40 @@ class BatchedDetector:
         hms = output["hm"][0]
         dets = {k: v.detach().cpu().numpy() for k, v in dets.items()}
         return (output, dets, forward_time, hms) if return_time else (output, dets)
+
+    # ---- the steps either side of the network, on the device ------------------
+    def render_inputs(self, prev_kp_projs, next_kp_projs, metas, has_prior=None):
+        """The four prior maps of ``SGTADetector._get_further_dt_pnp_inputs`` (sgta_detector.py:486-497) for a
+        batch, rendered on the device: prev_kp_projs / next_kp_projs [B,K,2] raw-image projections (the PnP outputs),
+        metas = list of the reference's ``meta`` dicts (trans_input, trans_output, inp_/out_ sizes, width, height).
+        -> (pre_hm [B,1,H,W], repro_hm, pre_hm_cls [B,K,h,w], repro_hm_cls)."""
+        import numpy as np
+        m0 = metas[0]
+        t_in = np.stack([m["trans_input"] for m in metas])
+        t_out = np.stack([m["trans_output"] for m in metas])
+        wh = np.array([[m["width"], m["height"]] for m in metas], np.int32)
+        dev = next(self.model.parameters()).device
+        kw = dict(has_prior=has_prior, device=dev)
+        iw, ih, ow, oh = m0["inp_width"], m0["inp_height"], m0["out_width"], m0["out_height"]
+        return (prepost.get_prev_hm_wo_noise(prev_kp_projs, t_in, iw, ih, wh, **kw),
+                prepost.get_prev_hm_wo_noise(next_kp_projs, t_in, iw, ih, wh, **kw),
+                prepost.get_prev_hm_wo_noise_cls(prev_kp_projs, t_out, ow, oh, wh, **kw),
+                prepost.get_prev_hm_wo_noise_cls(next_kp_projs, t_out, ow, oh, wh, **kw))
+
+    def post_process_device(self, dets, metas):
+        """``SGTADetector.post_process`` + ``_get_final_kps`` for a batch, on the device: dets = the device dict of
+        process_device; -> dict(valid, ct, ct_wreg, reg, tracking, final_kps [B,K,2] fp64) of device tensors.
+        ``final_kps`` feeds the next frame's PnP / prior rendering without leaving HBM."""
+        import numpy as np
+        t_inv = np.stack([prepost.get_affine_transform(m["c"], m["s"], 0, (m["out_width"], m["out_height"]), inv=1)
+                          .astype(np.float32) for m in metas])
+        return prepost.post_process_device(dets, t_inv, float(self.opt.out_thresh))
+
+    def post_process(self, dets, metas):
+        """Host-side view with the reference's structure: (list per sample of detection dicts, final_kps [B,K,2])."""
+        pp = {k: v.cpu().numpy() for k, v in self.post_process_device(dets, metas).items()}
+        dets_np = {k: v.detach().cpu().numpy() for k, v in dets.items()}
+        return prepost.dream_generic_post_process(dets_np, pp, self.K), pp["final_kps"]
 
     @staticmethod
     def keypoints(dets):

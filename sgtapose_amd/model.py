@@ -21,7 +21,8 @@ def default_opt(**over):
     """The ``opt`` fields the path reads at the inference script's values."""
     o = dict(head_kernel=3, prior_bias=-4.6, dla_node="dcn", load_model="x", pre_img=True, pre_hm=True,
              ct_modify=False, num_classes=7, pos_embed=True, model_output_list=False,
-             device=torch.device("cuda"), phase="PlanA_win", zero_tracking=False, flip_test=False)
+             device=torch.device("cuda"), phase="PlanA_win", zero_tracking=False, flip_test=False,
+             out_thresh=0.001)       # max(track_thresh 0.001, out_thresh -1): opts_parallel.py:212, 263, 333
     for i, ks in enumerate((12, 6, 3, 1, 1, 1), 1):
         o["k_list_%d" % i] = 1
         o["ks%d" % i] = ks

@@ -76,3 +76,44 @@ def decode_case():
     reg = torch.rand(2, 2, H, W, generator=g)
     trk = torch.randn(2, 2, H, W, generator=g)
     return hm, reg, trk
+
+
+def prepost_case():
+    """Inputs of the prior-rendering / post-processing fixtures (numpy, seeded): B samples with different raw image
+    sizes, key-points inside / outside the raw image, near the map border (patch skipped), on integer coordinates,
+    overlapping pairs, and a sample without priors; detections with scores around the threshold."""
+    import numpy as np
+    rng = np.random.RandomState(2023)
+    K, inp_w, inp_h, out_w, out_h = 7, 160, 128, 40, 32
+    raws = [(640, 480), (1280, 720), (160, 128), (333, 257), (640, 480)]
+    B = len(raws)
+    c = np.array([[w / 2.0, h / 2.0] for (w, h) in raws], np.float32)
+    s = np.array([max(w, h) * 1.0 for (w, h) in raws], np.float32)
+    prev = np.zeros((B, K, 2), np.float64)
+    nxt = np.zeros((B, K, 2), np.float64)
+    for b, (w, h) in enumerate(raws):
+        prev[b] = rng.uniform([0, 0], [w, h], size=(K, 2))
+        nxt[b] = prev[b] + rng.normal(0, 3.0, size=(K, 2))
+    prev[0, 0] = [-5.0, 100.0]                     # outside the raw image -> (0, 0) -> not drawn
+    prev[0, 1] = [639.999, 479.999]               # inside, lands near the map corner -> patch skipped
+    prev[0, 2] = [320.0, 240.0]                   # integer coordinates
+    prev[0, 3] = [322.0, 241.0]                   # overlaps key-point 2
+    prev[1, 0] = [1280.0, 10.0]                   # x == raw_width -> outside
+    prev[2, 4] = [20.0, 20.0]
+    prev[2, 5] = [4.2, 60.0]                      # x - radius >= 0 holds exactly / fails
+    prev[2, 6] = [3.9, 60.0]
+    nxt[3, :] = -3999.996                          # "missing" key-points of the previous step
+    has_prior = np.array([1, 1, 1, 1, 0], np.uint8)
+    scores = rng.uniform(0.0, 1.0, size=(B, K)).astype(np.float32)
+    scores[1, 2] = 0.01
+    scores[3, :] = -1.0                            # decode's "no peak" marker
+    xs = rng.randint(0, out_w, size=(B, K)).astype(np.int64)
+    ys = rng.randint(0, out_h, size=(B, K)).astype(np.int64)
+    regs = rng.uniform(0, 1, size=(B, K, 2, 1)).astype(np.float32)
+    trk = rng.normal(0, 2, size=(B, K, 2)).astype(np.float32)
+    dets = {"scores": scores, "clses": np.tile(np.arange(K, dtype=np.int64), (B, 1)),
+            "xs": xs, "ys": ys, "cts": np.stack([xs, ys], -1),
+            "cts_wreg": (np.stack([xs, ys], -1).astype(np.float32)[..., None] + regs).astype(np.float32),
+            "regs": regs, "tracking": trk}
+    return dict(K=K, inp_w=inp_w, inp_h=inp_h, out_w=out_w, out_h=out_h, raws=raws, c=c, s=s, prev=prev, nxt=nxt,
+                has_prior=has_prior, dets=dets, out_thresh=0.1)

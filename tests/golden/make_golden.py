@@ -137,7 +137,74 @@ def decode_ops():
     save("decode_ops.npz", **arrs)
 
 
+def prepost_ops():
+    """Prior rendering + post-processing from the reference's own utilities.py,
+    lib/utils/post_process.py and lib/sgta_detector.py.  cv2 is absent, so the affine matrices come from
+    oracle.prepost.get_affine_transform (unpinned) and are INPUTS of both sides; the reference's
+    ``get_affine_transform`` inside dream_generic_post_process is pointed at the same matrices."""
+    import ref_import
+    from types import SimpleNamespace
+    from oracle import prepost as op
+    load_reference()
+    ref_import._stub("ruamel")
+    ref_import._stub("ruamel.yaml", YAML=object)
+    ref_import._stub("progress")
+    ref_import._stub("progress.bar", Bar=object)
+    REF = ref_import.REF
+    util = ref_import._load("reflib.utilities", os.path.join(REF, "utilities.py"))
+    sys.modules["sgtapose"].utilities = util
+    ref_import._stub("reflib.utils")
+    image = ref_import._load("reflib.utils.image", os.path.join(REF, "lib/utils/image.py"))
+    ref_import._load("reflib.utils.ddd_utils", os.path.join(REF, "lib/utils/ddd_utils.py"))
+    pp = ref_import._load("reflib.utils.post_process", os.path.join(REF, "lib/utils/post_process.py"))
+    ref_import._stub("reflib.model.model", create_model=None, load_model=None, create_dream_hourglass=None)
+    ref_import._stub("reflib.utils.debugger", Debugger=object)
+    ref_import._stub("reflib.utils.tracker", Tracker=object)
+    det = ref_import._load("reflib.sgta_detector", os.path.join(REF, "lib/sgta_detector.py"))
+
+    cs = cases.prepost_case()
+    K, B = cs["K"], len(cs["raws"])
+    arrs = {}
+    t_in = np.stack([op.get_affine_transform(cs["c"][b], cs["s"][b], 0, [cs["inp_w"], cs["inp_h"]]) for b in range(B)])
+    t_out = np.stack([op.get_affine_transform(cs["c"][b], cs["s"][b], 0, [cs["out_w"], cs["out_h"]]) for b in range(B)])
+    t_inv = np.stack([op.get_affine_transform(cs["c"][b], cs["s"][b], 0, (cs["out_w"], cs["out_h"]), inv=1)
+                      for b in range(B)])
+    arrs.update(trans_input=t_in, trans_output=t_out, trans_inv=t_inv)
+    hms, clss, clips = [], [], []
+    for b, (rw, rh) in enumerate(cs["raws"]):
+        for nm, kps in (("prev", cs["prev"][b]), ("next", cs["nxt"][b])):
+            src = kps if cs["has_prior"][b] else None
+            hms.append(util.get_prev_hm_wo_noise(src, t_in[b], cs["inp_w"], cs["inp_h"], rw, rh))
+            clss.append(util.get_prev_hm_wo_noise_cls(src, np.zeros((K, 3)), t_out[b], cs["out_w"], cs["out_h"], rw, rh))
+            clips.append(util.affine_transform_and_clip(kps, t_in[b], cs["inp_w"], cs["inp_h"], rw, rh))
+    arrs["hm"] = np.stack(hms).reshape(B, 2, cs["inp_h"], cs["inp_w"])
+    arrs["hm_cls"] = np.stack(clss).reshape(B, 2, K, cs["out_h"], cs["out_w"])
+    arrs["clip"] = np.stack(clips).reshape(B, 2, K, 2)
+    # post-processing: the reference function with its affine matrix pinned to ours
+    mats = iter([t_inv[b] for b in range(B)])
+    pp.get_affine_transform = lambda *a, **k: next(mats)
+    opt = SimpleNamespace(out_thresh=cs["out_thresh"], num_classes=K)
+    dets = cs["dets"]
+    out = pp.dream_generic_post_process(opt, dets, [None] * B, [None] * B, cs["out_h"], cs["out_w"], K)
+    fake = SimpleNamespace(opt=opt, is_ct=True)
+    valid = np.zeros((B, K), np.uint8)
+    fields = {k: np.zeros((B, K, 2), np.float32) for k in ("ct", "ct_wreg", "reg", "tracking")}
+    final = np.zeros((B, K, 2), np.float64)
+    for b in range(B):
+        for item in out[b]:
+            j = item["class"] - 1
+            valid[b, j] = 1
+            for k in fields:
+                fields[k][b, j] = item[k]
+        final[b] = det.SGTADetector._get_final_kps(fake, out[b])
+    arrs.update(pp_valid=valid, final_kps=final, **{"pp_" + k: v for k, v in fields.items()})
+    save("prepost_ops.npz", **arrs)
+
+
 def main():
+    if "--prepost-only" in sys.argv:
+        prepost_ops()
+        return
     model, opt = build_reference_model()
     sd = model.state_dict()
     keys = [[k, list(v.shape)] for k, v in sd.items()]
@@ -148,6 +215,7 @@ def main():
     window_ops(model)
     encoder_ops(model)
     decode_ops()
+    prepost_ops()
     fullnet(model, "128", 2, 128, 128, 317, extra=True)
     fullnet(model, "128_first", 1, 128, 128, 318, first_frame=True)
     fullnet(model, "96x160", 1, 96, 160, 319)

@@ -421,3 +421,68 @@ def test_large_nonsquare_input_matches_oracle(model):
         assert out[k].shape == ref[k].shape
         err = float((out[k].cpu() - ref[k]).abs().max())
         assert err < 1e-3, (k, err)
+
+
+# ---- the steps either side of the network ---------------------------------------
+def _prepost_metas(cs, g):
+    metas = []
+    for b, (rw, rh) in enumerate(cs["raws"]):
+        metas.append(dict(c=cs["c"][b], s=cs["s"][b], width=rw, height=rh, inp_width=cs["inp_w"],
+                          inp_height=cs["inp_h"], out_width=cs["out_w"], out_height=cs["out_h"],
+                          trans_input=t(g["trans_input"][b]).numpy(), trans_output=t(g["trans_output"][b]).numpy()))
+    return metas
+
+
+def test_prior_rendering_matches_reference_bit_exact(ops):
+    """sgta_render_priors against the reference's get_prev_hm_wo_noise(_cls) outputs (golden): integer centres and
+    float32 Gaussian values, bit-exact; the host affine matrices equal the fixtures'."""
+    from sgtapose_amd import prepost
+    g = golden("prepost_ops.npz")
+    cs = cases.prepost_case()
+    B = len(cs["raws"])
+    t_in = np.stack([prepost.get_affine_transform(cs["c"][b], cs["s"][b], 0, [cs["inp_w"], cs["inp_h"]]) for b in range(B)])
+    t_out = np.stack([prepost.get_affine_transform(cs["c"][b], cs["s"][b], 0, [cs["out_w"], cs["out_h"]]) for b in range(B)])
+    assert np.array_equal(t_in, g["trans_input"]) and np.array_equal(t_out, g["trans_output"])
+    wh = np.array(cs["raws"], np.int32)
+    for q, kps in enumerate((cs["prev"], cs["nxt"])):
+        hm = prepost.get_prev_hm_wo_noise(kps, t_in, cs["inp_w"], cs["inp_h"], wh, cs["has_prior"], device=DEV)
+        hc = prepost.get_prev_hm_wo_noise_cls(kps, t_out, cs["out_w"], cs["out_h"], wh, cs["has_prior"], device=DEV)
+        assert hm.shape == (B, 1, cs["inp_h"], cs["inp_w"]) and hc.shape == (B, cs["K"], cs["out_h"], cs["out_w"])
+        assert np.array_equal(hm[:, 0].cpu().numpy(), g["hm"][:, q]), q
+        assert np.array_equal(hc.cpu().numpy(), g["hm_cls"][:, q]), q
+    with pytest.raises(ValueError):
+        prepost.get_prev_hm_wo_noise(np.full((1, 7, 2), np.nan), t_in[:1], 8, 8, wh[:1], device=DEV)
+
+
+def test_post_process_and_final_kps_match_reference(ops, model):
+    """sgta_post_process against dream_generic_post_process + _get_final_kps of the reference (golden): validity
+    and the missing marker exact, fp32 affine coordinates within 1 ulp of a 1e3-pixel value (2.5e-4)."""
+    from sgtapose_amd import prepost
+    from sgtapose_amd.detector import BatchedDetector
+    g = golden("prepost_ops.npz")
+    cs = cases.prepost_case()
+    dets = {k: torch.from_numpy(v).to(DEV) for k, v in cs["dets"].items()}
+    pp = prepost.post_process_device(dets, g["trans_inv"], cs["out_thresh"])
+    assert np.array_equal(pp["valid"].cpu().numpy(), g["pp_valid"])
+    valid = g["pp_valid"].astype(bool)
+    for k in ("ct", "ct_wreg", "reg", "tracking"):
+        got = pp[k].cpu().numpy()
+        assert np.allclose(got[valid], g["pp_" + k][valid], atol=2.5e-4, rtol=0), k
+    fk = pp["final_kps"].cpu().numpy()
+    assert fk.dtype == np.float64
+    assert np.array_equal(fk[~valid], g["final_kps"][~valid])                 # -999.999 * 4, exactly
+    assert np.allclose(fk[valid], g["final_kps"][valid], atol=2.5e-4, rtol=0)
+    # detector-level mirror: the reference's list-of-dicts structure and the rendered inputs through the metas
+    det = BatchedDetector(model, model.opt)
+    old = det.opt.out_thresh
+    det.opt.out_thresh = cs["out_thresh"]
+    try:
+        items, final = det.post_process(dets, _prepost_metas(cs, g))
+    finally:
+        det.opt.out_thresh = old
+    assert [len(x) for x in items] == g["pp_valid"].sum(1).tolist()
+    assert items[0][0]["class"] == 1 and set(items[0][0]) >= {"score", "ct", "ct_wreg", "reg", "tracking", "ct_output"}
+    assert np.allclose(final[valid], g["final_kps"][valid], atol=2.5e-4, rtol=0)
+    maps = det.render_inputs(cs["prev"], cs["nxt"], _prepost_metas(cs, g), has_prior=cs["has_prior"])
+    assert np.array_equal(maps[1][:, 0].cpu().numpy(), g["hm"][:, 1])
+    assert np.array_equal(maps[2].cpu().numpy(), g["hm_cls"][:, 0])

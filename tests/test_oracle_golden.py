@@ -139,3 +139,33 @@ def test_dcnv2_torch_oracle_matches_plain_c_witness():
         rc = lib.dcnv2_forward_ref(fp(x), fp(om), fp(w.contiguous()), fp(b), fp(y), B, Ci, H, W, Co)
         assert rc == 0
         assert torch.allclose(y, ref, atol=2e-5, rtol=1e-5), float((y - ref).abs().max())
+
+
+def test_prior_rendering_and_post_process_match_reference():
+    """oracle/prepost.py against the reference's utilities.py / post_process.py / sgta_detector.py outputs
+    (SURVEY.md section 8f rank 1).  Integer-centred float32 maps and the key-point table: bit-exact."""
+    from oracle import prepost as op
+    g = golden("prepost_ops.npz")
+    cs = cases.prepost_case()
+    K, B = cs["K"], len(cs["raws"])
+    for b, (rw, rh) in enumerate(cs["raws"]):
+        t_in = op.get_affine_transform(cs["c"][b], cs["s"][b], 0, [cs["inp_w"], cs["inp_h"]])
+        t_out = op.get_affine_transform(cs["c"][b], cs["s"][b], 0, [cs["out_w"], cs["out_h"]])
+        assert np.array_equal(t_in, g["trans_input"][b]) and np.array_equal(t_out, g["trans_output"][b])
+        for q, kps in enumerate((cs["prev"][b], cs["nxt"][b])):
+            src = kps if cs["has_prior"][b] else None
+            hm = op.get_prev_hm_wo_noise(src, t_in, cs["inp_w"], cs["inp_h"], rw, rh)
+            hc = op.get_prev_hm_wo_noise_cls(src, K, t_out, cs["out_w"], cs["out_h"], rw, rh)
+            assert np.array_equal(hm, g["hm"][b, q]), (b, q)
+            assert np.array_equal(hc, g["hm_cls"][b, q]), (b, q)
+            assert np.array_equal(op.affine_transform_and_clip(kps, t_in, cs["inp_w"], cs["inp_h"], rw, rh), g["clip"][b, q])
+    out = op.dream_generic_post_process(cs["dets"], g["trans_inv"], cs["out_thresh"])
+    for b in range(B):
+        valid = np.zeros(K, np.uint8)
+        for item in out[b]:
+            j = item["class"] - 1
+            valid[j] = 1
+            for k in ("ct", "ct_wreg", "reg", "tracking"):
+                assert np.array_equal(np.asarray(item[k], np.float32), g["pp_" + k][b, j]), (b, j, k)
+        assert np.array_equal(valid, g["pp_valid"][b])
+        assert np.array_equal(op.get_final_kps(out[b], K), g["final_kps"][b])
