@@ -160,15 +160,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
+    cfg_name = {(32, 480, 640): "configs[1]", (16, 736, 1280): "configs[3] (720p padded to a multiple of 32)"}.get(
+        (B, H, W), "custom")
     result = {
-        "metric": "frame-pairs/sec @480x640",
+        "metric": "frame-pairs/sec @%dx%d" % (args.height, args.width),
         "value": round(world * B * args.steps / el, 3),
         "unit": "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * el / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: batch=%d 2-frame %dx%d synthetic pairs per GPU, dlapawdl3new_34 "
+        "config": {"workload": cfg_name + ": batch=%d 2-frame %dx%d synthetic pairs per GPU, dlapawdl3new_34 "
                                "random-init (seeded), full backbone + temporal attention (6 levels) + DCN neck + "
                                "heads + sigmoid + peak decode%s" % (B, H, W, " + RCCL all-gather of keypoints" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": world * B, "net_input": [H, W],
