@@ -265,19 +265,39 @@ class Engine:
         return fid0
 
     # ------------------------------------------------------------------------------------------
-    def _deform(self, name, x, out):
-        om = self.vbuf("om", x.B, 27, x.H, x.W)
+    def _deform(self, name, x, out, om_name="om"):
+        om = self.vbuf(om_name, x.B, 27, x.H, x.W)
         ops.conv2d(x, self.P[name + ".om"], om, ACT_NONE)
         return ops.dcn_v2(x, om, self.P[name], out, ACT_RELU)
 
     def _ida(self, ida, name, layers, startp, endp):
-        """IDAUp.forward (dla.py:571-577) on a list of Views; new buffers for every node output."""
+        """IDAUp.forward (dla.py:571-577) on a list of Views; new buffers for every node output.
+        ``proj_j(layers[i])`` only reads the level as it was when the call started, so the projections of the later
+        iterations (small maps that fill a fraction of the chip) run on a second stream beside the node chain."""
+        main = torch.cuda.current_stream()
+        side = self._neck_stream() if (self.use_side_stream and _lib.PROFILE is None and endp - startp > 2) else None
+        early = {}
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for i in range(startp + 2, endp):
+                    j = i - startp
+                    x = layers[i]
+                    p = self._deform("%s.proj_%d" % (name, j), x, self.vbuf("%s.p%d" % (name, j), x.B, ida.o, x.H, x.W),
+                                     om_name="%s.om%d" % (name, j))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    early[i] = (p, ev)
         for i in range(startp + 1, endp):
             j = i - startp
             x = layers[i]
             o = ida.o
             f = ida.up_f[j]
-            p = self._deform("%s.proj_%d" % (name, j), x, self.vbuf("ida_p", x.B, o, x.H, x.W))
+            if i in early:
+                p, ev = early[i]
+                main.wait_event(ev)
+            else:
+                p = self._deform("%s.proj_%d" % (name, j), x, self.vbuf("ida_p", x.B, o, x.H, x.W))
             u = ops.upsample_add(p, self.P["%s.up_%d" % (name, j)], layers[i - 1],
                                  self.vbuf("ida_u", x.B, o, x.H * f, x.W * f), f)
             layers[i] = self._deform("%s.node_%d" % (name, j), u, self.vbuf("%s.n%d" % (name, j), x.B, o, u.H, u.W))
@@ -367,6 +387,11 @@ class Engine:
             if dead_on_side:
                 main.wait_stream(side)             # the step is complete only when the side work is
             return out
+
+    def _neck_stream(self):
+        if getattr(self, "_side2", None) is None:
+            self._side2 = torch.cuda.Stream(device=self.dev)
+        return self._side2
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
