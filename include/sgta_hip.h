@@ -65,10 +65,15 @@ int sgta_conv3x3s1_f32(const float* x, long x_bs, const float* wt, const float* 
  * u : host-transformed weights U = G g G^T, packed [Cin/8][8][Cout_pad][20]: element (c/8, c%8, co, p) with the 16
  *     positions p = 4*xi + nu first, then 4 pad floats (80-byte rows: conflict-free 16-byte LDS reads).
  * tile in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2-pixel output tiles per work-group (64 tiles x 32
- * output channels; persistent work-groups, two per CU).  One image (Cin*H*W*4 bytes) must fit 31 bits. */
+ * output channels; persistent work-groups, two per CU).  One image (Cin*H*W*4 bytes) must fit 31 bits.
+ * ws / ws_floats: optional workspace (may be NULL / 0).  With act = 0 and no residual, a layer whose (block,
+ * channel group) items leave most CUs idle (the 27-channel DCN offset convs of levels 4-5) is split over up to 8
+ * slices of the input channels; the slices' partial sums (<= 8*B*Cout*H*W floats) meet in ws and are reduced in a
+ * fixed order -- results do not depend on the split being taken. */
 int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float* bias, const float* res,
                           long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
-                          int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);
+                          int Cout_pad, int act, int res_mode, int tile, float* ws, long ws_floats,
+                          sgta_stream_t stream);
 
 /* Same contract with Winograd F(4x4,3x3) in fp32 (interpolation points 0, +-1, +-2, inf): 4x fewer MFMA cycles
  * than a direct convolution; results differ from it at the 1e-5 level.  Needs W % 4 == 0, Cin % 4 == 0, 16-byte

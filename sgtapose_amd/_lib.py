@@ -20,7 +20,7 @@ SIGNATURES = {
     "sgta_conv2d_f32": [_p, _l, _p, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_conv3x3s1_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_conv_c16_f32": [_p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _p],
-    "sgta_conv3x3_wino_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_conv3x3_wino_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _l, _p],
     "sgta_conv3x3_wino4_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_conv1x1_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_conv1x1_skinny_f32": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],

@@ -30,6 +30,8 @@ struct WinoArgs {
   float* y;        long y_bs;
   int B, Cin, H, W, Cout, Cout_pad;
   int nchunks, blk_r, blk_c, n_ct, n_pt, vec;      // vec: 4 / 2 / 1 pixels per store
+  int ksplit;                      // > 1: item = (block, channel group, K slice); raw partial sums go to ``part``
+  float* part;                     // [ksplit][B][Cout][H][W]
 };
 
 // padded, de-interleaved window row length: 2*WWP == 32/(32/TC) (mod 32) puts the tile rows of a 16-lane group on
@@ -60,8 +62,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   // the last chunk and the register epilogue of the current one run.
   const int G = gridDim.x;
   const int wg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int n_items = a.n_pt * a.n_ct;
+  const int n_items = a.n_pt * a.n_ct * a.ksplit;
   if (wg >= n_items) return;
+  const int nch = a.nchunks / a.ksplit;              // chunks per item (split-K: a slice of the input channels)
+  int kbase = 0;                                     // first chunk of the item being STAGED
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, tl = lane & 15;
@@ -102,7 +106,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #endif
   // per-item staging parameters (scalar item -> image, block origin, channel group)
   auto setup = [&](int item) {
-    const int pt = item / a.n_ct, ct = item - pt * a.n_ct;
+    const int ks = item % a.ksplit, rest = item / a.ksplit;
+    const int pt = rest / a.n_ct, ct = rest - pt * a.n_ct;
+    kbase = ks * nch;
     const int b = pt / blks, rem = pt - b * blks;
     const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
     const int oy0 = 2 * br * TR, ox0 = 2 * bc * TC;
@@ -130,13 +136,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int q = 0; q < ROUNDS; ++q)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + c * WSZP + (q < ROUNDS - 1 ? q * 256 : WSZP - 256)),
-                                                   4, poff[q], (kc * CK + c) * HW * 4, 0, 0);
+                                                   4, poff[q], ((kbase + kc) * CK + c) * HW * 4, 0, 0);
     } else {
       float* udst = lds + st * STAGE + CK * WSZP + wave * 256;
 #pragma unroll
       for (int q = 0; q < U_PER; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + q * 1024), 16, uoff[q],
-                                                 kc * CK * a.Cout_pad * LDU * 4, 0, 0);
+                                                 (kbase + kc) * CK * a.Cout_pad * LDU * 4, 0, 0);
     }
 #endif
   };
@@ -197,11 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int p = 0; p < 16; ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[p][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ct = item % a.n_ct;
+    const int ks = item % a.ksplit, ct = (item / a.ksplit) % a.n_ct;
     f32x4 bsv[2];                                     // bias of this lane's 8 output channels (i*16 + 4g + r)
     bool more = true;
-    for (int kc = 0; kc < a.nchunks; ++kc) {
-      const bool last = kc + 1 >= a.nchunks;
+    for (int kc = 0; kc < nch; ++kc) {
+      const bool last = kc + 1 >= nch;
       int nkc = kc + 1;
       if (last) {
         // last chunk of the item: its staging registers are free -> point them at the next item and put that
@@ -210,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         nkc = 0;
         if (more) setup(item + G);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) bsv[i] = *reinterpret_cast<const f32x4*>(a.bias + ct * BM + i * 16 + 4 * g);
+        for (int i = 0; i < 2; ++i)
+          bsv[i] = a.ksplit > 1 ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                : *reinterpret_cast<const f32x4*>(a.bias + ct * BM + i * 16 + 4 * g);
       }
       const bool dma = more;
       if (dma) stage(nkc, sidx ^ 1, 0);
@@ -250,10 +258,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 
     // ---- output transform in registers: lane = tile t, output channels i*16 + 4g + r -----------------------
     {
-      const int pt = item / a.n_ct;
+      const int pt = item / (a.ksplit * a.n_ct);
       const int b = pt / blks, rem = pt - b * blks;
       const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
       const int oy = 2 * br * TR + 2 * trow, ox = 2 * bc * TC + 2 * tcol;
+      // split-K: raw partial sums (no bias; launched as ACT = RES = 0) go to slice ks of the workspace
+      float* const ybase = a.ksplit > 1 ? a.part + (long)ks * a.B * a.Cout * HW : a.y;
+      const long ybs = a.ksplit > 1 ? (long)a.Cout * HW : a.y_bs;
       if (a.vec == 4) {
         // 16-byte stores: the lanes of two horizontally adjacent tiles trade halves, the even one stores the
         // four pixels of the upper row, the odd one those of the lower row (W % 4 == 0: a pair is inside the
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
               if (ACT == 2) o4[q] = sigmoidf_(o4[q]);
               if (RES == 2) o4[q] += rr[q];
             }
-            *reinterpret_cast<f32x4*>(a.y + (long)b * a.y_bs + o) = o4;
+            *reinterpret_cast<f32x4*>(ybase + (long)b * ybs + o) = o4;
           }
       } else if (oy < H && ox < W) {
         const bool x1 = ox + 1 < W, y1 = oy + 1 < H;
@@ -309,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
             float v[4] = {(ra[0] + ra[1]) + ra[2] + bs, (rb[0] + rb[1]) + rb[2] + bs,
                           (ra[1] - ra[2]) - ra[3] + bs, (rb[1] - rb[2]) - rb[3] + bs};
             const long o = (long)co * HW + oy * W + ox;
-            float* yp = a.y + (long)b * a.y_bs + o;
+            float* yp = ybase + (long)b * ybs + o;
             float rr4[4] = {0.f, 0.f, 0.f, 0.f};
             if (RES) {
               const float* rp = a.res + (long)b * a.res_bs + o;
@@ -348,8 +359,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   }
 }
 
+// split-K epilogue: y = bias + sum_s part[s] in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void wino_splitk_reduce_kernel(const float* __restrict__ part, int S,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 long y_bs, int Cout, int HW, long per_slice) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= per_slice) return;
+  const int p = (int)(i % HW);
+  const long t = i / HW;
+  const int co = (int)(t % Cout), b = (int)(t / Cout);
+  float v = bias[co];
+  for (int s = 0; s < S; ++s) v += part[s * per_slice + i];
+  y[b * y_bs + (long)co * HW + p] = v;
+}
+
 template <int ACT, int RES>
-static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
+static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) {
   auto go = [&](auto kern, int TC) -> int {
     const int TR = 64 / TC;
     a.n_ct = a.Cout_pad / 32;
@@ -367,11 +392,30 @@ static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
         return SGTA_EBADARG;
       resident = cus * per_cu;
     }
-    const long items = (long)a.n_pt * a.n_ct;
+    long items = (long)a.n_pt * a.n_ct;
+    // split-K: a layer with few items (small map, <= 32 output channels, many input channels: the DCN offset convs
+    // of levels 4-5) leaves most CUs idle; slices of the input channels become extra items, their raw partial sums
+    // meet in the caller's workspace and are reduced in a fixed order
+    a.ksplit = 1;
+    if (ACT == 0 && RES == 0 && a.part) {
+      const long per_slice = (long)a.B * a.Cout * a.H * a.W;
+      for (int s = 8; s >= 2; s >>= 1)
+        if (items * s <= resident && a.nchunks % s == 0 && a.nchunks / s >= 4 && per_slice * s <= a_ws_floats) {
+          a.ksplit = s;
+          break;
+        }
+    }
+    items *= a.ksplit;
     int grid = (int)(items < resident ? items : resident);
     grid = cdiv(grid, 8) * 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
     SGTA_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+      const long per_slice = (long)a.B * a.Cout * a.H * a.W;
+      hipLaunchKernelGGL(wino_splitk_reduce_kernel, dim3((unsigned)((per_slice + 255) / 256)), dim3(256), 0, st, a.part,
+                         a.ksplit, a.bias, a.y, a.y_bs, a.Cout, a.H * a.W, per_slice);
+      SGTA_LAUNCH_CHECK();
+    }
     return SGTA_OK;
   };
   // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2 output tiles
@@ -387,7 +431,7 @@ static int launch_wino(WinoArgs& a, int tile, hipStream_t st) {
 extern "C" int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float* bias,
                                       const float* res, long res_bs, float* y, long y_bs, int B, int Cin,
                                       int H, int W, int Cout, int Cout_pad, int act, int res_mode, int tile,
-                                      hipStream_t st) {
+                                      float* ws, long ws_floats, hipStream_t st) {
   if (!x || !u || !bias || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return SGTA_EBADARG;
   if (Cin % 8 || Cout_pad % 32 || Cout_pad < Cout) return SGTA_EBADARG;
   if ((res_mode != 0) != (res != nullptr) || (long)Cin * H * W > 0x7fffffffL) return SGTA_EBADARG;
@@ -396,16 +440,18 @@ extern "C" int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, 
   WinoArgs a{};
   a.x = x; a.x_bs = x_bs; a.u = u; a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 8;
+  a.ksplit = 1; a.part = ws;
+  const long wsf = ws ? ws_floats : 0;
   // 16- / 8-byte stores and residual loads need widths and plane alignments that are multiples of 4 / 2 pixels
   auto aligned = [&](int n) {
     return (W % n == 0) && (y_bs % n == 0) && (((uintptr_t)y & (4 * n - 1)) == 0) &&
            (!res || ((res_bs % n == 0) && (((uintptr_t)res & (4 * n - 1)) == 0)));
   };
   a.vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
-  if (act == 1 && res_mode == 0) return launch_wino<1, 0>(a, tile, st);
-  if (act == 0 && res_mode == 0) return launch_wino<0, 0>(a, tile, st);
-  if (act == 1 && res_mode == 1) return launch_wino<1, 1>(a, tile, st);
-  if (act == 1 && res_mode == 2) return launch_wino<1, 2>(a, tile, st);
-  if (act == 2 && res_mode == 0) return launch_wino<2, 0>(a, tile, st);
+  if (act == 1 && res_mode == 0) return launch_wino<1, 0>(a, tile, wsf, st);
+  if (act == 0 && res_mode == 0) return launch_wino<0, 0>(a, tile, wsf, st);
+  if (act == 1 && res_mode == 1) return launch_wino<1, 1>(a, tile, wsf, st);
+  if (act == 1 && res_mode == 2) return launch_wino<1, 2>(a, tile, wsf, st);
+  if (act == 2 && res_mode == 0) return launch_wino<2, 0>(a, tile, wsf, st);
   return SGTA_EBADARG;
 }

@@ -301,9 +301,14 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
             meta = _conv_meta(pc, out, 2, False)
             meta["kernel"] = "conv3x3_wino_kernel<%d>" % (32, 16, 8, 4)[code]
             meta["exec_flops"] = meta["flops"] * 16.0 / 36.0      # F(2x2,3x3): 16 of 36 multiplies
+        ws, nws = None, 0
+        if act == ACT_NONE and res is None and pc.Cout_pad == 32:      # split-K candidates: the DCN offset convs
+            nws = 8 * x.B * pc.Cout * x.H * x.W
+            ws = _splitk_ws(out.base.device, nws)
         _lib.call("sgta_conv3x3_wino_f32", x.ptr, x.bs, pc.u_wino.data_ptr(), pc.bias.data_ptr(), rp, rbs,
                   out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
-                  res_mode if res is not None else 0, code, _stream(), meta=meta)
+                  res_mode if res is not None else 0, code, None if ws is None else ws.data_ptr(), nws, _stream(),
+                  meta=meta)
         return out
     pt = pc.patch_tile(x.W, tile, x.H * x.W) if USE_PATCH_KERNEL else 0
     if pt:
@@ -318,6 +323,20 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
               act, res_mode if res is not None else 0, tile, _stream(),
               meta=_conv_meta(pc, out, tile, False) if _lib.PROFILE is not None else None)
     return out
+
+
+_SPLITK_WS = {}
+
+
+def _splitk_ws(dev, nfloats):
+    """Workspace of the split-K Winograd path: one buffer per (device, stream) -- layers on different streams run
+    concurrently -- grown on demand (<= 8*B*27*H*W floats for the level-4/5 offset convs)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    t = _SPLITK_WS.get(key)
+    if t is None or t.numel() < nfloats:
+        t = _SPLITK_WS[key] = torch.empty(nfloats, dtype=torch.float32, device=dev)
+    return t
 
 
 USE_WINO4 = True               # F(4x4,3x3) where the map fills its 64-tile blocks (else F(2x2,3x3))

@@ -88,6 +88,29 @@ def test_conv3x3_implementations_agree(ops, cin, cout, H, W):
         ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.USE_WINO4, ops.WINO4_MIN_FILL = flags
 
 
+@pytest.mark.parametrize("cin,H,W", [(512, 15, 20), (256, 30, 40), (64, 9, 7)])
+def test_winograd_split_k_offset_conv(ops, cin, H, W):
+    """The 27-channel DCN offset convs of the small levels are split over slices of the input channels (few work
+    items otherwise); the fixed-order reduction must reproduce the plain convolution and be run-to-run identical."""
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(27, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(27, generator=g) * 0.1
+    ref = F.conv2d(x, w, bias, padding=1)
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV))
+    old = ops.USE_WINO4
+    ops.USE_WINO4 = False
+    try:
+        a = torch.zeros(ref.shape, device=DEV)
+        b = torch.zeros(ref.shape, device=DEV)
+        ops.conv2d(x.to(DEV), pc, a, ops.ACT_NONE)
+        ops.conv2d(x.to(DEV), pc, b, ops.ACT_NONE)
+    finally:
+        ops.USE_WINO4 = old
+    assert torch.equal(a, b)
+    assert float((a.cpu() - ref).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(16, 32, 48, 64), (64, 128, 24, 40), (256, 512, 30, 40), (32, 64, 17, 23)])
 def test_conv3x3_stride2_kernel(ops, cin, cout, H, W):
     g = torch.Generator().manual_seed(cin + H)

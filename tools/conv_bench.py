@@ -32,6 +32,8 @@ SHAPES = [
     ("heads0", "conv", 64, 768, 3, 1, 120, 160, 32),
     ("om_64", "conv", 64, 27, 3, 1, 120, 160, 32),
     ("om_128", "conv", 128, 27, 3, 1, 60, 80, 32),
+    ("om_256", "conv", 256, 27, 3, 1, 30, 40, 32),
+    ("om_512", "conv", 512, 27, 3, 1, 15, 20, 32),
     ("dcn_64_64", "dcn", 64, 64, 3, 1, 120, 160, 32),
     ("dcn_128_64", "dcn", 128, 64, 3, 1, 60, 80, 32),
     ("dcn_128_128", "dcn", 128, 128, 3, 1, 60, 80, 32),
