@@ -71,14 +71,16 @@ def instrumented_pass(run_step, steps):
     return agg
 
 
-def cpu_baseline(sd, H, W, budget_s=20.0):
-    """The CPU oracle (kind 'port') on B=1 frame pairs of the same workload, all host cores."""
+def cpu_baseline(sd, H, W, det=None, dev=None, budget_s=20.0):
+    """The CPU oracle (kind 'port') on B=1 frame pairs of the same workload, all host cores; the same sample then
+    goes through the HIP path and the heat-map / key-point deviation is reported beside the timing ('parity')."""
+    import numpy as np
     import oracle
     from sgtapose_amd.synthetic import make_inputs
     cores = torch.get_num_threads()
     inp = make_inputs(1, H, W, seed=999)
     a = [inp[k] for k in ARGS]
-    oracle.process_reference(sd, *a)                       # warm-up
+    ref_out, ref_dets = oracle.process_reference(sd, *a)   # warm-up (and the parity reference)
     n, t0 = 0, time.perf_counter()
     while True:
         oracle.process_reference(sd, *a)
@@ -86,9 +88,35 @@ def cpu_baseline(sd, H, W, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 16:
             break
-    return {"value": round(n / el, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d x (B=1, %dx%d) frame pairs through oracle.process_reference (forward + sigmoid + "
-                      "decode), %d torch threads, %.1f s" % (n, H, W, cores, el)}
+    res = {"value": round(n / el, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d x (B=1, %dx%d) frame pairs through oracle.process_reference (forward + sigmoid + "
+                     "decode), %d torch threads, %.1f s" % (n, H, W, cores, el)}
+    if det is not None:
+        out, dets = det.process_device(*[t.to(dev) for t in a])
+        kp_hip = det.keypoints(dets)[0].cpu().numpy().astype(np.float64)           # [7, 3] = x, y, score
+        kp_ref = np.concatenate([ref_dets["cts_wreg"][0].reshape(7, 2), ref_dets["scores"][0].reshape(7, 1)], 1)
+        found = kp_ref[:, 2] >= 0
+        res["parity"] = {
+            "hm_max_abs": float((out["hm"].cpu() - ref_out["hm"]).abs().max()),
+            "reg_max_abs": float((out["reg"].cpu() - ref_out["reg"]).abs().max()),
+            "tracking_max_abs": float((out["tracking"].cpu() - ref_out["tracking"]).abs().max()),
+            "keypoints_found_ref": int(found.sum()),
+            "keypoints_found_same": bool(np.array_equal(found, kp_hip[:, 2] >= 0)),
+            "keypoint_l2_max_px": float(np.sqrt(((kp_hip[found, :2] - kp_ref[found, :2]) ** 2).sum(1)).max()) if found.any() else 0.0,
+            "bar": "1e-3 abs (north_star); same seeded sample through the CPU oracle and the HIP path"}
+        # random-init logits are flat (no peaks): key-point parity of the decode on peaked maps fed to both decoders
+        from sgtapose_amd.decode import dream_generic_decode
+        from sgtapose_amd.synthetic import peaked_heatmaps
+        hm, _ = peaked_heatmaps(4, H // 4, W // 4, seed=7)
+        reg, trk = ref_out["reg"].repeat(4, 1, 1, 1), ref_out["tracking"].repeat(4, 1, 1, 1)
+        got = dream_generic_decode({"hm": hm.to(dev), "reg": reg.to(dev), "tracking": trk.to(dev)}, K=7)
+        ref = oracle.dream_decode({"hm": hm, "reg": reg, "tracking": trk})
+        d = (got["cts_wreg"].cpu().double() - ref["cts_wreg"].double()).reshape(-1, 2)
+        res["parity"]["decode_peaked_maps"] = {
+            "keypoints": int((ref["scores"] > 0).sum()),
+            "integer_peaks_identical": bool(torch.equal(got["xs"].cpu(), ref["xs"]) and torch.equal(got["ys"].cpu(), ref["ys"])),
+            "keypoint_l2_max_px": float(d.pow(2).sum(1).sqrt().max())}
+    return res
 
 
 def main():
@@ -215,7 +243,7 @@ def main():
         result["other_kernels_ms"] = {k: round(a["ms"], 3) for k, a in rows if not a["flops"]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sd, H, W)
+        result["cpu_baseline"] = cpu_baseline(sd, H, W, det, dev)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
