@@ -71,6 +71,26 @@ def instrumented_pass(run_step, steps):
     return agg
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/r01_pmc_step_by_kernel.csv:
+    separate ``rocprofv3 --pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` runs of this same command, see profiles/README.md),
+    with the guide's gfx950 correction (FETCH_SIZE tallies the 128-byte requests of 16-B/lane streams -- the window
+    and weight LDS-DMA of this kernel -- at 64 bytes: doubled).  bench.py cannot collect PMCs itself; None if the
+    table or the kernel is missing."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_step_by_kernel.csv")
+    try:
+        import csv
+        for r in csv.DictReader(open(path)):
+            if r["kernel"] == kernel:
+                n = int(r["launches"])
+                byts = (2.0 * float(r["FETCH_SIZE_MB_raw"]) + float(r["WRITE_SIZE_MB_raw"])) * 1e6 / n
+                return round(byts), ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) / %d launches of one step, "
+                                     "profiles/r01_pmc_step_by_kernel.csv (separate --pmc passes; not collected live)" % n)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, "no PMC table for this kernel under profiles/"
+
+
 def cpu_baseline(sd, H, W, det=None, dev=None, budget_s=20.0):
     """The CPU oracle (kind 'port') on B=1 frame pairs of the same workload, all host cores; the same sample then
     goes through the HIP path and the heat-map / key-point deviation is reported beside the timing ('parity')."""
@@ -230,6 +250,7 @@ def main():
                                       "the matrix-pipe utilisation",
                               "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
                               "share_of_step": round(ta["ms"] / tot, 3)}
+        result["roofline"]["traffic"], result["roofline"]["traffic_note"] = pmc_traffic(top)
         extra = []
         for k, a in rows:
             if a["flops"]:

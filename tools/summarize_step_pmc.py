@@ -19,22 +19,36 @@ def load(d):
     return by
 
 
+def family(name):
+    fam = name.split("<")[0]
+    if "wino" in fam and "<" in name:                 # keep the tile shape: same spelling as bench.py's table
+        fam += "<%s>" % name.split("<")[1].split(",")[0].strip()
+    return fam
+
+
+def last_step(by):
+    """Dispatches of the last step: everything from the second-to-last stem launch on.  The passes are separate
+    runs and the side streams interleave differently in each, so they are summed per kernel family, never paired."""
+    keys = list(by.keys())
+    start = [i for i, k in enumerate(keys) if k[1].startswith("stem_c16")][-2]
+    return [(k[1], by[k]) for k in keys[start:]]
+
+
 def main():
-    sq, fe, wr = load(sys.argv[1]), load(sys.argv[2]), load(sys.argv[3])
-    keys, fk, wk = list(sq.keys()), list(fe.keys()), list(wr.keys())
-    start = [i for i, k in enumerate(keys) if k[1].startswith("stem_c16")][-2]      # first kernel of the last step
+    sq, fe, wr = (last_step(load(d)) for d in sys.argv[1:4])
     agg = collections.OrderedDict()
-    for idx in range(start, len(keys)):
-        k, v = keys[idx], sq[keys[idx]]
-        a = agg.setdefault(k[1].split("<")[0], dict(n=0, mfma=0.0, gui=0.0, fetch=0.0, write=0.0))
+    for name, v in sq:
+        a = agg.setdefault(family(name), dict(n=0, mfma=0.0, gui=0.0, fetch=0.0, write=0.0))
         a["n"] += 1
         a["mfma"] += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
         a["gui"] += v.get("GRBM_GUI_ACTIVE", 0) / 8
-        if idx < len(fk) and fk[idx][1] == k[1]:
-            a["fetch"] += fe[fk[idx]].get("FETCH_SIZE", 0)
-        if idx < len(wk) and wk[idx][1] == k[1]:
-            a["write"] += wr[wk[idx]].get("WRITE_SIZE", 0)
-    lines = ["kernel,launches,cycles_per_XCD,mfma_pipe_util,FETCH_SIZE_MB_raw,WRITE_SIZE_MB_raw,HBM_GBs_at_2GHz"]
+    for name, v in fe:
+        if family(name) in agg:
+            agg[family(name)]["fetch"] += v.get("FETCH_SIZE", 0)
+    for name, v in wr:
+        if family(name) in agg:
+            agg[family(name)]["write"] += v.get("WRITE_SIZE", 0)
+    lines = ["kernel,launches,cycles_per_XCD,mfma_pipe_util,FETCH_SIZE_MB_raw,WRITE_SIZE_MB_raw,HBM_GBs_at_2GHz_raw"]
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["gui"]):
         if a["gui"] < 2e4 or not name.strip():
             continue
