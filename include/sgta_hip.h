@@ -79,8 +79,9 @@ int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, const float
  * than a direct convolution; results differ from it at the 1e-5 level.  Needs W % 4 == 0, Cin % 4 == 0, 16-byte
  * aligned x / y / res / bias and batch strides % 4 == 0 (else SGTA_EBADARG: use sgta_conv3x3_wino_f32).
  * u : host-transformed weights U = G g G^T (6x6), packed [Cin/4][4][Cout_pad][36]: element (c/4, c%4, co, 6*xi + nu).
- * tile in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 4x4-pixel output tiles per work-group (64 tiles x 16
- * output channels; persistent work-groups, two per CU).  Cout_pad % 16 == 0. */
+ * tile in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 4x4-pixel output tiles per work-group (64 tiles x 32
+ * output channels, 8 waves, one persistent work-group per CU; 64 x 16 / 4 waves / two per CU when Cout_pad % 32 != 0).
+ * Cout_pad % 16 == 0. */
 int sgta_conv3x3_wino4_f32(const float* x, long x_bs, const float* u, const float* bias, const float* res,
                           long res_bs, float* y, long y_bs, int B, int Cin, int H, int W, int Cout,
                           int Cout_pad, int act, int res_mode, int tile, sgta_stream_t stream);

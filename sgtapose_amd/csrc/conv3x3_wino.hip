@@ -21,6 +21,7 @@
 // that the stride-2 tile pattern reads unit-stride) and U chunk arrive by buffer LDS-DMA through a 2-stage ring.
 // fp32 throughout: the transforms only add and halve, error stays at the 1e-6 level (<< 1e-3).
 #include "common.h"
+#include <cstdlib>
 
 struct WinoArgs {
   const float* x;  long x_bs;
@@ -45,13 +46,17 @@ __device__ __forceinline__ float wino_swap_adjacent(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-template <int TC, int ACT, int RES>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
-  constexpr int BM = 32, CK = 8, TR = 64 / TC;
+// NCG = output-channel groups (of 32) per work-group: 1 -> 4 waves, two work-groups per CU; 2 -> 8 waves, one
+// work-group per CU whose two channel groups share the staged window (fewer bytes through the memory pipeline per MFMA:
+// the measured limiter beside MFMA issue).
+template <int TC, int ACT, int RES, int NCG>
+__global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
+  constexpr int NT = 256 * NCG, BM = 32 * NCG, CK = 8, TR = 64 / TC;
   constexpr int WH = 2 * TR + 2, WW = 2 * TC + 2, NE = WW / 2, WWP = wino_wwp(TC);
   constexpr int WSZ = WH * WWP, WSZP = wino_pad16(WSZ), ROUNDS = (WSZP + 255) / 256;
-  constexpr int LDU = 20, U_F = CK * BM * LDU, U_PER = U_F / 4 / 256;
-  static_assert(U_F % 1024 == 0, "U stage must be a whole number of 256 x 16-byte slots");
+  constexpr int LDU = 20, U_F = CK * BM * LDU, U_PER = U_F / 4 / NT;
+  static_assert(U_F % (NT * 4) == 0, "U stage must be a whole number of NT x 16-byte slots");
+  constexpr int CPW = CK / NCG;                      // window channels staged by each 4-wave half of the work-group
   constexpr int STAGE = CK * WSZP + U_F;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
@@ -68,13 +73,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   int kbase = 0;                                     // first chunk of the item being STAGED
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave >> 2, tgw = wave & 3;          // channel group / tile group of this wave
+  const int tid4 = tid & 255;                        // thread id inside the 4-wave half (window staging)
   const int g = lane >> 4, tl = lane & 15;
   const int H = a.H, W = a.W, HW = H * W;
   const int blks = a.blk_r * a.blk_c;
-  const int t = wave * 16 + tl;                      // this lane's tile inside the 64-tile block
+  const int t = tgw * 16 + tl;                       // this lane's tile inside the 64-tile block
   const int trow = t / TC, tcol = t % TC;
   const int tbase = (2 * trow) * WWP + tcol;
-  const int poffl = tbase + g * WSZP, uoffl = CK * WSZP + (g * BM + tl) * LDU;
+  const int poffl = tbase + g * WSZP, uoffl = CK * WSZP + (g * BM + cg * 32 + tl) * LDU;
 
   // ---- LDS-DMA staging through buffer loads: per-slot byte offsets are chunk- and channel-invariant VGPRs,
   // the channel / chunk advance is a scalar offset, and out-of-image slots carry an out-of-range offset that
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   for (int q = 0; q < ROUNDS; ++q) {
     // the last round is shifted back to end exactly at WSZP (it re-writes a few slots of the previous round
     // with identical data): every DMA runs with all 256 lanes, no divergent control flow around M0
-    const int e = tid + (q < ROUNDS - 1 ? q * 256 : WSZP - 256);
+    const int e = tid4 + (q < ROUNDS - 1 ? q * 256 : WSZP - 256);
     const int r = e / WWP, sx = e - r * WWP;
     const bool ok = e < WSZ && sx < WW;
     slot_r[q] = ok ? r - 1 : -0x10000;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   int uslot[U_PER];
 #pragma unroll
   for (int q = 0; q < U_PER; ++q) {
-    const int e = tid + q * 256;                     // 16-byte slot: channel c = e / (BM*5), then (co, quarter)
+    const int e = tid + q * NT;                      // 16-byte slot: channel c = e / (BM*5), then (co, quarter)
     const int c = e / (BM * 5), rem = e - c * (BM * 5);
     uslot[q] = (c * a.Cout_pad * LDU + rem * 4) * 4;
   }
@@ -130,18 +137,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   auto stage = [&](int kc, int st, int part) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (part < 2) {
-      float* dst = lds + st * STAGE + wave * 64;
+      // each 4-wave half of the work-group stages CPW of the chunk's channels (all 8 when NCG == 1)
+      float* dst = lds + st * STAGE + tgw * 64;
 #pragma unroll
-      for (int c = part * (CK / 2); c < (part + 1) * (CK / 2); ++c)
+      for (int cc = part * (CPW / 2); cc < (part + 1) * (CPW / 2); ++cc) {
+        const int c = cg * CPW + cc;
 #pragma unroll
         for (int q = 0; q < ROUNDS; ++q)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + c * WSZP + (q < ROUNDS - 1 ? q * 256 : WSZP - 256)),
                                                    4, poff[q], ((kbase + kc) * CK + c) * HW * 4, 0, 0);
+      }
     } else {
       float* udst = lds + st * STAGE + CK * WSZP + wave * 256;
 #pragma unroll
       for (int q = 0; q < U_PER; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + q * 1024), 16, uoff[q],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + q * NT * 4), 16, uoff[q],
                                                  (kbase + kc) * CK * a.Cout_pad * LDU * 4, 0, 0);
     }
 #endif
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           bsv[i] = a.ksplit > 1 ? f32x4{0.f, 0.f, 0.f, 0.f}
-                                : *reinterpret_cast<const f32x4*>(a.bias + ct * BM + i * 16 + 4 * g);
+                                : *reinterpret_cast<const f32x4*>(a.bias + ct * BM + cg * 32 + i * 16 + 4 * g);
       }
       const bool dma = more;
       if (dma) stage(nkc, sidx ^ 1, 0);
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int co = ct * BM + i * 16 + 4 * g + r;
+            const int co = ct * BM + cg * 32 + i * 16 + 4 * g + r;
             if (co >= a.Cout) continue;
             float ra[4], rb[4];
 #pragma unroll
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int co = ct * BM + i * 16 + 4 * g + r;
+            const int co = ct * BM + cg * 32 + i * 16 + 4 * g + r;
             if (co >= a.Cout) continue;
             float ra[4], rb[4];
 #pragma unroll
@@ -373,11 +383,11 @@ __global__ __launch_bounds__(256) void wino_splitk_reduce_kernel(const float* __
   y[b * y_bs + (long)co * HW + p] = v;
 }
 
-template <int ACT, int RES>
+template <int ACT, int RES, int NCG>
 static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) {
   auto go = [&](auto kern, int TC) -> int {
     const int TR = 64 / TC;
-    a.n_ct = a.Cout_pad / 32;
+    a.n_ct = a.Cout_pad / (32 * NCG);
     a.blk_r = cdiv(cdiv(a.H, 2), TR);
     a.blk_c = cdiv(cdiv(a.W, 2), TC);
     a.n_pt = a.B * a.blk_r * a.blk_c;
@@ -388,7 +398,7 @@ static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) 
       int dev = 0, cus = 0, per_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256 * NCG, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
         return SGTA_EBADARG;
       resident = cus * per_cu;
     }
@@ -408,7 +418,7 @@ static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) 
     items *= a.ksplit;
     int grid = (int)(items < resident ? items : resident);
     grid = cdiv(grid, 8) * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * NCG), 0, st, a);
     SGTA_LAUNCH_CHECK();
     if (a.ksplit > 1) {
       const long per_slice = (long)a.B * a.Cout * a.H * a.W;
@@ -420,10 +430,10 @@ static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) 
   };
   // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 2x2 output tiles
   switch (tile) {
-    case 0: return go(conv3x3_wino_kernel<32, ACT, RES>, 32);
-    case 1: return go(conv3x3_wino_kernel<16, ACT, RES>, 16);
-    case 2: return go(conv3x3_wino_kernel<8, ACT, RES>, 8);
-    case 3: return go(conv3x3_wino_kernel<4, ACT, RES>, 4);
+    case 0: return go(conv3x3_wino_kernel<32, ACT, RES, NCG>, 32);
+    case 1: return go(conv3x3_wino_kernel<16, ACT, RES, NCG>, 16);
+    case 2: return go(conv3x3_wino_kernel<8, ACT, RES, NCG>, 8);
+    case 3: return go(conv3x3_wino_kernel<4, ACT, RES, NCG>, 4);
   }
   return SGTA_EBADARG;
 }
@@ -448,10 +458,14 @@ extern "C" int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, 
            (!res || ((res_bs % n == 0) && (((uintptr_t)res & (4 * n - 1)) == 0)));
   };
   a.vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
-  if (act == 1 && res_mode == 0) return launch_wino<1, 0>(a, tile, wsf, st);
-  if (act == 0 && res_mode == 0) return launch_wino<0, 0>(a, tile, wsf, st);
-  if (act == 1 && res_mode == 1) return launch_wino<1, 1>(a, tile, wsf, st);
-  if (act == 1 && res_mode == 2) return launch_wino<1, 2>(a, tile, wsf, st);
-  if (act == 2 && res_mode == 0) return launch_wino<2, 0>(a, tile, wsf, st);
+  // two 32-channel groups per work-group (shared window): measured +7 % on the 120x160 maps but -5 % on the 15x20
+  // ones (half the items) and neutral at 30x40 -- the maps this kernel serves -- so it is opt-in (SGTA_WINO_NCG=2)
+  static const bool allow_wide = getenv("SGTA_WINO_NCG") && atoi(getenv("SGTA_WINO_NCG")) == 2;
+  const bool wide = allow_wide && (Cout_pad % 64 == 0);
+  if (act == 1 && res_mode == 0) return wide ? launch_wino<1, 0, 2>(a, tile, wsf, st) : launch_wino<1, 0, 1>(a, tile, wsf, st);
+  if (act == 0 && res_mode == 0) return wide ? launch_wino<0, 0, 2>(a, tile, wsf, st) : launch_wino<0, 0, 1>(a, tile, wsf, st);
+  if (act == 1 && res_mode == 1) return wide ? launch_wino<1, 1, 2>(a, tile, wsf, st) : launch_wino<1, 1, 1>(a, tile, wsf, st);
+  if (act == 1 && res_mode == 2) return wide ? launch_wino<1, 2, 2>(a, tile, wsf, st) : launch_wino<1, 2, 1>(a, tile, wsf, st);
+  if (act == 2 && res_mode == 0) return wide ? launch_wino<2, 0, 2>(a, tile, wsf, st) : launch_wino<2, 0, 1>(a, tile, wsf, st);
   return SGTA_EBADARG;
 }

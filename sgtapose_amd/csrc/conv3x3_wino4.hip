@@ -12,13 +12,16 @@
 // Ownership as in conv3x3_wino.hip: a wave owns 16 tiles x 16 output channels for ALL 36 positions (36
 // accumulators of the f32 MFMA 16x16x4 = 144 registers); lane (g = lane / 16, t = lane % 16) reads the raw
 // 6x6 window of tile t / channel g, transforms it in registers (144 VALU ops) and feeds 36 MFMAs; the output
-// transform, bias, residual, activation and 16-byte row stores run in registers.  Work-groups are 4 waves
-// (64 tiles x 16 channels), persistent, two per CU.
+// transform, bias, residual, activation and 16-byte row stores run in registers.  Work-groups are persistent:
+// 8 waves = 64 tiles x 32 channels, one per CU (two 16-channel groups share the staged window: the bytes moved
+// through the memory pipeline per MFMA, not DMA issue or latency, are what this kernel pays for beside its issue
+// time), or 4 waves = 64 tiles x 16 channels, two per CU, for layers without a second channel group.
 // The window is stored LINEARLY (row-major, origin 4 columns left of the block): with 4-pixel tiles a lane's
 // middle four columns are one aligned ds_read_b128, its first / last column comes from the neighbouring lane
 // by DPP row shift (LDS only for the lanes at a tile-row edge), and the window arrives by 16-BYTE buffer
 // LDS-DMA (image rows are 16-byte aligned: W % 4 == 0 is required).
 #include "common.h"
+#include <cstdlib>
 
 struct Wino4Args {
   const float* x;  long x_bs;
@@ -62,16 +65,18 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
   y[3] = fmaf(8.0f, s4, s2) + m[5];
 }
 
-template <int TC, int ACT, int RES>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
-  constexpr int BM = 16, CK = 4, TR = 64 / TC, EDGE = TC < 16 ? TC : 16;
+// NCG = output-channel groups (of 16) per work-group: 1 -> 4 waves, two work-groups per CU; 2 -> 8 waves, one work-group
+// per CU whose two channel groups share the staged window (35 % fewer bytes through the memory pipeline per MFMA).
+template <int TC, int ACT, int RES, int NCG>
+__global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_kernel(Wino4Args a) {
+  constexpr int NT = 256 * NCG, BM = 16 * NCG, CK = 4, TR = 64 / TC, EDGE = TC < 16 ? TC : 16;
   // channel plane stride == 8 (mod 32): the four channels of a wave's edge-lane reads (4-byte, a few lanes) use
   // different banks
   constexpr int WH = 4 * TR + 2, WWL = w4_wwl(TC), WQR = WWL / 4;
   constexpr int WSZ = WH * WWL + ((8 - (WH * WWL) % 32) + 32) % 32, WQ = WSZ / 4;
-  constexpr int P_SLOTS = CK * WQ, P_PER = (P_SLOTS + 255) / 256;          // 16-byte window slots per stage
-  constexpr int LDU = 36, U_F = CK * BM * LDU, U_SLOTS = U_F / 4, U_PER = (U_SLOTS + 255) / 256;
-  static_assert(P_SLOTS >= 256 && U_SLOTS >= 256, "a DMA round must be full");
+  constexpr int P_SLOTS = CK * WQ, P_PER = (P_SLOTS + NT - 1) / NT;        // 16-byte window slots per stage
+  constexpr int LDU = 36, U_F = CK * BM * LDU, U_SLOTS = U_F / 4, U_PER = (U_SLOTS + NT - 1) / NT;
+  static_assert(P_SLOTS >= NT && U_SLOTS >= NT, "a DMA round must be full");
   constexpr int STAGE = P_SLOTS * 4 + U_F;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
@@ -82,14 +87,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
   if (wg >= n_items) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave >> 2, tgw = wave & 3;          // channel group / tile group of this wave
   const int g = lane >> 4, tl = lane & 15;
   const int H = a.H, W = a.W, HW = H * W;
   const int blks = a.blk_r * a.blk_c;
-  const int t = wave * 16 + tl;                      // this lane's tile inside the 64-tile block
+  const int t = tgw * 16 + tl;                       // this lane's tile inside the 64-tile block
   const int trow = t / TC, tcol = t % TC;
   const bool edge_l = (tl % EDGE) == 0, edge_r = (tl % EDGE) == EDGE - 1;
   const int poffl = g * WSZ + (4 * trow) * WWL + 4 * tcol + 4;            // middle quad of the lane's first row
-  const int uoffl = CK * WSZ + (g * BM + tl) * LDU;
+  const int uoffl = CK * WSZ + (g * BM + cg * 16 + tl) * LDU;
 
   // ---- buffer LDS-DMA staging (16-byte slots; out-of-image slots carry an out-of-range offset -> zeros) ------
   unsigned poff[P_PER], uoff[U_PER];
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
     const int oy0 = 4 * br * TR, ox0 = 4 * bc * TC;
 #pragma unroll
     for (int q = 0; q < P_PER; ++q) {
-      const int e = tid + (q < P_PER - 1 ? q * 256 : P_SLOTS - 256);     // last round shifted back (full waves)
+      const int e = tid + (q < P_PER - 1 ? q * NT : P_SLOTS - NT);       // last round shifted back (full waves)
       const int c = e / WQ, rq = e - c * WQ;
       const int r = rq / WQR, qx = rq - r * WQR;
       const int gy = oy0 - 1 + r, gx = ox0 - 4 + 4 * qx;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
     }
 #pragma unroll
     for (int q = 0; q < U_PER; ++q) {
-      const int e = tid + (q < U_PER - 1 ? q * 256 : U_SLOTS - 256);
+      const int e = tid + (q < U_PER - 1 ? q * NT : U_SLOTS - NT);
       const int c = e / (BM * 9), rem = e - c * (BM * 9);                 // 9 x 16 bytes per (channel, output channel)
       uoff[q] = (unsigned)((c * a.Cout_pad + ct * BM) * LDU + rem * 4) * 4u;
     }
@@ -131,13 +137,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
       float* dst = lds + st * STAGE + wave * 256;
 #pragma unroll
       for (int q = 0; q < P_PER; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + (q < P_PER - 1 ? q * 1024 : P_SLOTS * 4 - 1024)),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + (q < P_PER - 1 ? q * NT * 4 : P_SLOTS * 4 - NT * 4)),
                                                  16, poff[q], kc * CK * HW * 4, 0, 0);
     } else {
       float* udst = lds + st * STAGE + P_SLOTS * 4 + wave * 256;
 #pragma unroll
       for (int q = 0; q < U_PER; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + (q < U_PER - 1 ? q * 1024 : U_SLOTS * 4 - 1024)),
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + (q < U_PER - 1 ? q * NT * 4 : U_SLOTS * 4 - NT * 4)),
                                                  16, uoff[q], kc * CK * a.Cout_pad * LDU * 4, 0, 0);
     }
 #endif
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
         more = item + G < n_items;
         nkc = 0;
         if (more) setup(item + G);
-        bsv = *reinterpret_cast<const f32x4*>(a.bias + ct * BM + 4 * g);
+        bsv = *reinterpret_cast<const f32x4*>(a.bias + ct * BM + cg * 16 + 4 * g);
       }
       if (more) stage(nkc, sidx ^ 1, 0);
       const float* wp = lds + sidx * STAGE + poffl;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
       if (oy < H && ox < W) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int co = ct * BM + 4 * g + r;
+          const int co = ct * BM + cg * 16 + 4 * g + r;
           if (co >= a.Cout) continue;
           float R[6][4];                             // A^T along nu for every xi
 #pragma unroll
@@ -287,11 +293,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino4_kernel(Wino4Args a) {
   }
 }
 
-template <int ACT, int RES>
+template <int ACT, int RES, int NCG>
 static int launch_wino4(Wino4Args& a, int tile, hipStream_t st) {
   auto go = [&](auto kern, int TC) -> int {
     const int TR = 64 / TC;
-    a.n_ct = a.Cout_pad / 16;
+    a.n_ct = a.Cout_pad / (16 * NCG);
     a.blk_r = cdiv(cdiv(a.H, 4), TR);
     a.blk_c = cdiv(cdiv(a.W, 4), TC);
     a.n_pt = a.B * a.blk_r * a.blk_c;
@@ -301,23 +307,23 @@ static int launch_wino4(Wino4Args& a, int tile, hipStream_t st) {
       int dev = 0, cus = 0, per_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess ||
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256 * NCG, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
         return SGTA_EBADARG;
       resident = cus * per_cu;
     }
     const long items = (long)a.n_pt * a.n_ct;
     int grid = (int)(items < resident ? items : resident);
     grid = cdiv(grid, 8) * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * NCG), 0, st, a);
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   };
   // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 4x4 output tiles
   switch (tile) {
-    case 0: return go(conv3x3_wino4_kernel<32, ACT, RES>, 32);
-    case 1: return go(conv3x3_wino4_kernel<16, ACT, RES>, 16);
-    case 2: return go(conv3x3_wino4_kernel<8, ACT, RES>, 8);
-    case 3: return go(conv3x3_wino4_kernel<4, ACT, RES>, 4);
+    case 0: return go(conv3x3_wino4_kernel<32, ACT, RES, NCG>, 32);
+    case 1: return go(conv3x3_wino4_kernel<16, ACT, RES, NCG>, 16);
+    case 2: return go(conv3x3_wino4_kernel<8, ACT, RES, NCG>, 8);
+    case 3: return go(conv3x3_wino4_kernel<4, ACT, RES, NCG>, 4);
   }
   return SGTA_EBADARG;
 }
@@ -338,10 +344,14 @@ extern "C" int sgta_conv3x3_wino4_f32(const float* x, long x_bs, const float* u,
   Wino4Args a{};
   a.x = x; a.x_bs = x_bs; a.u = u; a.bias = bias; a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 4;
-  if (act == 1 && res_mode == 0) return launch_wino4<1, 0>(a, tile, st);
-  if (act == 0 && res_mode == 0) return launch_wino4<0, 0>(a, tile, st);
-  if (act == 1 && res_mode == 1) return launch_wino4<1, 1>(a, tile, st);
-  if (act == 1 && res_mode == 2) return launch_wino4<1, 2>(a, tile, st);
-  if (act == 2 && res_mode == 0) return launch_wino4<2, 0>(a, tile, st);
+  // two channel groups per work-group (shared window: +5-10 % measured on every layer shape of the workload)
+  // whenever the layer has them; SGTA_WINO4_NCG=1 forces the 4-wave form
+  static const bool allow_wide = !(getenv("SGTA_WINO4_NCG") && atoi(getenv("SGTA_WINO4_NCG")) == 1);
+  const bool wide = allow_wide && (Cout_pad % 32 == 0);
+  if (act == 1 && res_mode == 0) return wide ? launch_wino4<1, 0, 2>(a, tile, st) : launch_wino4<1, 0, 1>(a, tile, st);
+  if (act == 0 && res_mode == 0) return wide ? launch_wino4<0, 0, 2>(a, tile, st) : launch_wino4<0, 0, 1>(a, tile, st);
+  if (act == 1 && res_mode == 1) return wide ? launch_wino4<1, 1, 2>(a, tile, st) : launch_wino4<1, 1, 1>(a, tile, st);
+  if (act == 1 && res_mode == 2) return wide ? launch_wino4<1, 2, 2>(a, tile, st) : launch_wino4<1, 2, 1>(a, tile, st);
+  if (act == 2 && res_mode == 0) return wide ? launch_wino4<2, 0, 2>(a, tile, st) : launch_wino4<2, 0, 1>(a, tile, st);
   return SGTA_EBADARG;
 }
