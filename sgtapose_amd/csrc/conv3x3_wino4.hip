@@ -70,10 +70,11 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 template <int TC, int ACT, int RES, int NCG>
 __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_kernel(Wino4Args a) {
   constexpr int NT = 256 * NCG, BM = 16 * NCG, CK = 4, TR = 64 / TC, EDGE = TC < 16 ? TC : 16;
-  // channel plane stride == 8 (mod 32): the four channels of a wave's edge-lane reads (4-byte, a few lanes) use
-  // different banks
+  // channel plane stride == 0 (mod 64 floats = one 256-byte bank row): ds_read_b128 is served in four 16-lane groups
+  // that each mix tiles of two channel planes (lanes {0-3,12-15,20-27}, ...); with the planes bank-aligned and the
+  // tile-row stride WWL == 8 / 12 (mod 16 slots) every group covers 16 distinct 16-byte slots (conflict-free)
   constexpr int WH = 4 * TR + 2, WWL = w4_wwl(TC), WQR = WWL / 4;
-  constexpr int WSZ = WH * WWL + ((8 - (WH * WWL) % 32) + 32) % 32, WQ = WSZ / 4;
+  constexpr int WSZ = (WH * WWL + 63) / 64 * 64, WQ = WSZ / 4;
   constexpr int P_SLOTS = CK * WQ, P_PER = (P_SLOTS + NT - 1) / NT;        // 16-byte window slots per stage
   constexpr int LDU = 36, U_F = CK * BM * LDU, U_SLOTS = U_F / 4, U_PER = (U_SLOTS + NT - 1) / NT;
   static_assert(P_SLOTS >= NT && U_SLOTS >= NT, "a DMA round must be full");
@@ -185,13 +186,16 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
         dl[i] = w4_from_left(mid[i][3]);
         dr[i] = w4_from_right(mid[i][0]);
       }
-      if (edge_l) {
+      if (edge_l || edge_r) {
+        // a lane at a tile-row edge reads the neighbouring quad of the halo itself: ONE 16-byte read per row serves
+        // both kinds of edge lane (4-byte reads of these few lanes would all hit one bank)
+        const int eo = edge_l ? -4 : 4;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dl[i] = wp[i * WWL - 1];
-      }
-      if (edge_r) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) dr[i] = wp[i * WWL + 4];
+        for (int i = 0; i < 6; ++i) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(wp + i * WWL + eo);
+          if (edge_l) dl[i] = q[3];
+          else dr[i] = q[0];
+        }
       }
       // V = B^T d B: transform along i (rows of d) for each column j, then along j
       float T[6][6], V[36];
