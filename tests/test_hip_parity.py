@@ -509,3 +509,76 @@ def test_post_process_and_final_kps_match_reference(ops, model):
     maps = det.render_inputs(cs["prev"], cs["nxt"], _prepost_metas(cs, g), has_prior=cs["has_prior"])
     assert np.array_equal(maps[1][:, 0].cpu().numpy(), g["hm"][:, 1])
     assert np.array_equal(maps[2].cpu().numpy(), g["hm_cls"][:, 0])
+
+
+# ---- seeded random sweeps: every dispatch path of ops.conv2d / ops.dcn_v2 on shapes nobody hand-picked --------------
+def test_conv2d_random_shape_sweep(ops):
+    """60 seeded random layers (3x3 stride 1/2, 1x1; odd / tiny / wide maps; any channel counts; all epilogues) against
+    torch: exercises F(4x4,3x3) in both work-group forms, F(2x2,3x3) incl. split-K, the stride-2, 1x1, skinny and
+    generic kernels and their fall-backs through the same dispatcher the engine uses."""
+    rng = np.random.RandomState(20231003)
+    g = torch.Generator().manual_seed(99)
+    worst = 0.0
+    for case in range(60):
+        ks, stride = [(3, 1), (3, 1), (3, 1), (3, 2), (1, 1)][rng.randint(5)]
+        cin = int(rng.choice([3, 4, 8, 12, 16, 24, 32, 40, 64, 96, 128, 256]))
+        cout = int(rng.choice([2, 7, 16, 27, 32, 33, 48, 64, 96, 128, 200]))
+        H = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 30, 33, 60]))
+        W = int(rng.choice([2, 3, 4, 6, 8, 12, 20, 23, 40, 64, 132]))
+        if ks == 3 and stride == 2 and (H < 2 or W < 2):
+            H, W = max(H, 2), max(W, 2)
+        B = int(rng.choice([1, 2, 3]))
+        act = int(rng.choice([0, 1, 1, 2]))
+        use_res = ks == 3 and stride == 1 and act == 1 and rng.rand() < 0.5
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(x, w, bias, stride=stride, padding=ks // 2)
+        res = torch.randn(ref.shape, generator=g) if use_res else None
+        if use_res:
+            ref = ref + res
+        ref = {0: ref, 1: F.relu(ref), 2: torch.sigmoid(ref)}[act]
+        pc = ops.PackedConv(w.to(DEV), bias.to(DEV), stride=stride)
+        out = torch.full(ref.shape, float("nan"), device=DEV)
+        ops.conv2d(x.to(DEV), pc, out, act, res=None if res is None else res.to(DEV), res_mode=1 if use_res else 0)
+        err = float((out.cpu() - ref).abs().max())
+        assert err == err and err < 2e-4, (case, ks, stride, cin, cout, H, W, B, act, use_res, err)
+        worst = max(worst, err)
+    assert worst < 2e-4
+
+
+def test_dcn_random_shape_sweep(ops):
+    """12 seeded random deformable layers (odd maps, offsets up to +-8 pixels: in-window and global-fallback samples)
+    against the oracle's DCNv2 restatement."""
+    rng = np.random.RandomState(7)
+    g = torch.Generator().manual_seed(5)
+    for case in range(12):
+        cin = int(rng.choice([4, 8, 32, 64, 128]))
+        cout = int(rng.choice([8, 64, 100, 128]))
+        H, W = int(rng.choice([3, 8, 15, 24, 31])), int(rng.choice([2, 9, 20, 33, 48]))
+        scale = float(rng.choice([0.3, 1.0, 4.0]))
+        x = torch.randn(2, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+        bias = torch.randn(cout, generator=g) * 0.1
+        om = torch.randn(2, 27, H, W, generator=g) * scale
+        col = oracle.dcn_v2_im2col(x, om[:, :18], torch.sigmoid(om[:, 18:27]))          # [B,Ci,9,H,W]
+        ref = F.relu(torch.matmul(w.reshape(cout, cin * 9), col.reshape(2, cin * 9, H * W)).view(2, cout, H, W)
+                     + bias.view(1, cout, 1, 1))
+        pc = ops.PackedConv(w.to(DEV), bias.to(DEV), tap_major=True)
+        out = torch.full(ref.shape, float("nan"), device=DEV)
+        ops.dcn_v2(x.to(DEV), om.to(DEV), pc, out, ops.ACT_RELU)
+        err = float((out.cpu() - ref).abs().max())
+        assert err == err and err < 2e-4, (case, cin, cout, H, W, scale, err)
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(1, 64, 96, 11), (2, 160, 128, 12), (3, 96, 224, 13), (1, 256, 64, 14)])
+def test_fullnet_random_sizes_match_oracle(model, B, H, W, seed):
+    """Whole network at sizes with no golden vector (different Winograd block shapes, split-K, tile fall-backs per
+    level) against the CPU oracle, incl. a first-frame (empty prior) sample."""
+    from sgtapose_amd.synthetic import make_inputs
+    inp = make_inputs(B, H, W, seed=seed, first_frame=(seed == 14))
+    out = model(*[inp[k].to(DEV) for k in ARGS])[-1]
+    ref = oracle.plan_a_window_forward(golden_state_dict(), *[inp[k] for k in ARGS])
+    for k in ("hm", "reg", "tracking"):
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        assert out[k].shape == ref[k].shape and err < 1e-3, (k, err)
