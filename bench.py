@@ -37,11 +37,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(dev, seed=0):
+def build_model(dev, seed=0, arch="dlapawdl3new_34"):
     from util import golden_state_dict
     from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
-    sd = golden_state_dict(seed)
-    model = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
+    if arch == "dlapawd3_34":                     # three-frame variant
+        heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+        sd = golden_state_dict(seed, keys="model_keys_three.json")
+        model = create_model(arch, heads, default_head_conv(heads), default_opt())
+    else:
+        sd = golden_state_dict(seed)
+        model = create_model(arch, DEFAULT_HEADS, default_head_conv(), default_opt())
     model.load_state_dict(sd, strict=True)
     return model.to(dev).eval(), sd
 
@@ -147,6 +152,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frame pairs per GPU per step")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--arch", default="dlapawdl3new_34", choices=["dlapawdl3new_34", "dlapawd3_34"],
+                    help="dlapawd3_34 = the reference's three-frame variant (frame triples/s; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--early-levels", default=None,
@@ -175,13 +182,21 @@ def main():
     from sgtapose_amd.detector import BatchedDetector
     from sgtapose_amd.synthetic import make_inputs
     B, H, W = args.batch, args.height, args.width
-    model, sd = build_model(dev)
+    model, sd = build_model(dev, arch=args.arch)
+    three = args.arch == "dlapawd3_34"
+    if three:
+        args.no_cpu_baseline = True                 # the CPU baseline / parity leg is the two-frame oracle's
     model.engine().compute_dead_levels = not args.skip_dead_levels
     if args.early_levels is not None:
         model.engine().early_levels = tuple(int(v) for v in args.early_levels.split(",") if v != "")
     det = BatchedDetector(model)
-    inp = make_inputs(B, H, W, seed=317 + rank * B)            # this rank's shard of the global batch
-    dev_in = [inp[k].to(dev) for k in ARGS]
+    if three:
+        from sgtapose_amd.synthetic import THREE_ARGS, make_inputs_three
+        inp = make_inputs_three(B, H, W, seed=317 + rank * B)
+        dev_in = [inp[k].to(dev) for k in THREE_ARGS]
+    else:
+        inp = make_inputs(B, H, W, seed=317 + rank * B)        # this rank's shard of the global batch
+        dev_in = [inp[k].to(dev) for k in ARGS]
     from sgtapose_amd.distributed import gather_keypoints
     state = {}
 
@@ -210,10 +225,12 @@ def main():
 
     cfg_name = {(32, 480, 640): "configs[1]", (16, 736, 1280): "configs[3] (720p padded to a multiple of 32)"}.get(
         (B, H, W), "custom")
+    if three:
+        cfg_name = "three-frame variant dlapawd3_34 (seq_len 3: the reference's widest; towards configs[4])"
     result = {
-        "metric": "frame-pairs/sec @%dx%d" % (args.height, args.width),
+        "metric": "%s/sec @%dx%d" % ("frame-triples" if three else "frame-pairs", args.height, args.width),
         "value": round(world * B * args.steps / el, 3),
-        "unit": "frame-pairs/s",
+        "unit": "frame-triples/s" if three else "frame-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * el / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

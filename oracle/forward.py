@@ -66,6 +66,56 @@ def plan_a_window_forward(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm
         return out
 
 
+# ---- DLA_PlanAWindow_Three: two previous frames ------------------------------------------
+HEADS_THREE = ("hm", "reg", "wh", "tracking")      # BaseModelPlanA_Three keeps 'wh' (base_model.py:213-262)
+
+
+def temporal_levels_three(x_ppre, x_pre, x_cur, ppre_hm_cls, pre_hm_cls, repro_hm_cls, sd, ks=KS_DEFAULT,
+                          use_pos=True, shared_ca=False):
+    """DLA_PlanAWindow_Three.imgpre2feats, temporal part (dla.py:1411-1447).  Levels 0-2: the current-frame window
+    tokens attend to the windows of BOTH previous frames (one encoder per frame unless ``shared_ca``), the two
+    outputs are concatenated (2C) and substituted through cat_layer (3C -> 6C -> C).  Levels 3-5: cat_layer runs
+    on EVERY pixel of cat[pre, pre, cur] -- the reference assigns ``ppre_f = pre_feats`` (:1435), kept."""
+    ppre_idx, pre_idx, cur_idx = topk_index(ppre_hm_cls), topk_index(pre_hm_cls), topk_index(repro_hm_cls)
+    out = list(x_cur)
+    for i in range(6):
+        ppre_f, pre_f, cur_f = x_ppre[i], x_pre[i], x_cur[i]
+        H, W = cur_f.shape[2:]
+        if i <= 2:
+            scale = (4, 2, 1)[i]
+            key_pp = window_gather(ppre_f, window_coords(ppre_idx, scale, ks[i], H, W))
+            key_p = window_gather(pre_f, window_coords(pre_idx, scale, ks[i], H, W))
+            cur_fid = window_coords(cur_idx, scale, ks[i], H, W)
+            qry = window_gather(cur_f, cur_fid)
+            tf_pp = "prev_transformer.%d" % i if shared_ca else "pprev_transformer.%d" % i
+            o_pp = encoder_forward(qry, key_pp, key_pp, sd, tf_pp, use_pos=use_pos)
+            o_p = encoder_forward(qry, key_p, key_p, sd, "prev_transformer.%d" % i, use_pos=use_pos)
+            out[i] = substitute_tokens(torch.cat([o_pp, o_p], dim=-1), cur_f, cur_fid, sd, "cat_layer.%d" % i)
+        else:
+            p = "cat_layer.%d" % i
+            pf, cf = pre_f.permute(0, 2, 3, 1).contiguous(), cur_f.permute(0, 2, 3, 1).contiguous()
+            z = torch.cat([pf, pf, cf], dim=-1)
+            z = F.linear(F.relu(F.linear(z, sd[p + ".0.weight"], sd[p + ".0.bias"])), sd[p + ".2.weight"], sd[p + ".2.bias"])
+            out[i] = z.permute(0, 3, 1, 2).contiguous()
+    return out
+
+
+def plan_a_window_three_forward(sd, x, ppre_img, pre_img, ppre_hm, pre_hm, repro_hm, ppre_hm_cls, pre_hm_cls,
+                                repro_hm_cls, ks=KS_DEFAULT, use_pos=True, shared_ca=False):
+    """BaseModelPlanA_Three.forward (base_model.py:267-299) over DLA_PlanAWindow_Three.imgpre2feats (dla.py:1400-1456)
+    -> {'hm','reg','wh','tracking'} logits."""
+    with torch.no_grad():
+        x_ppre = dla34_backbone(ppre_img, ppre_hm, sd)
+        x_pre = dla34_backbone(pre_img, pre_hm, sd)
+        x_cur = dla34_backbone(x, repro_hm, sd)
+        x_out = temporal_levels_three(x_ppre, x_pre, x_cur, ppre_hm_cls, pre_hm_cls, repro_hm_cls, sd, ks, use_pos,
+                                      shared_ca)
+        ups = dla_up_forward(x_out, sd)
+        y = [ups[0].clone(), ups[1].clone(), ups[2].clone()]
+        ida_up_forward(y, 0, 3, sd, "ida_up")
+        return {h: head_forward(y[-1], sd, h) for h in HEADS_THREE}
+
+
 def process_reference(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, K=7, **kw):
     """SGTADetector.process for phase PlanA_win: forward, in-place sigmoid on 'hm', decode.
     Returns (output dict with post-sigmoid hm, dets dict of numpy arrays)."""

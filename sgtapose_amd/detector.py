@@ -15,11 +15,12 @@ class BatchedDetector:
         self.K = int(self.opt.num_classes)
 
     @torch.no_grad()
-    def process_device(self, images, pre_images, pre_hms, repro_hms, pre_hms_cls, repro_hms_cls, static=False):
-        """Returns (output with post-sigmoid hm, dets as device tensors); nothing leaves the GPU."""
+    def process_device(self, *inputs, static=False):
+        """Returns (output with post-sigmoid hm, dets as device tensors); nothing leaves the GPU.  ``inputs`` = the
+        model's forward arguments: (images, pre_images, pre_hms, repro_hms, pre_hms_cls, repro_hms_cls) for
+        dlapawdl3new, the nine tensors of BaseModelPlanA_Three.forward for dlapawd3."""
         eng = self.model.engine()
-        out = eng.forward(images, pre_images, pre_hms, repro_hms, pre_hms_cls, repro_hms_cls,
-                          hm_act=ops.ACT_SIGMOID, static=static)
+        out = eng.forward(*inputs, hm_act=ops.ACT_SIGMOID, static=static)
         hm = out["hm"]
         ws = (eng.buf("dec_tmp", tuple(hm.shape)), eng.buf("dec_filt", tuple(hm.shape)))
         dets = dream_generic_decode(out, K=self.K, opt=self.opt, ws=ws)

@@ -93,19 +93,10 @@ class Engine:
         pack_ida(m.ida_up, "ida_up")
 
         f = lambda t: t.detach().float().contiguous()
-        self.tf = []
-        for i in range(3):
-            lay = m.transformer[i].layers[0]
-            ca = lay.cross_attn
-            self.tf.append(dict(
-                wq=f(ca.w_q.weight), wkv=torch.cat([f(ca.w_k.weight), f(ca.w_v.weight)], 0).contiguous(),
-                fc_w=f(ca.fc.weight), fc_b=f(ca.fc.bias), pos=f(ca.pos_embed) if self.use_pos else None,
-                ln1=(f(lay.norm1.weight), f(lay.norm1.bias)), ln3=(f(lay.norm3.weight), f(lay.norm3.bias)),
-                w1=f(lay.linear1.weight), b1=f(lay.linear1.bias), w2=f(lay.linear2.weight), b2=f(lay.linear2.bias),
-                n=ca.n, C=ca.inp_dim, hid=ca.hid_dim))
+        self.tf = [self._pack_encoder(m.transformer[i]) for i in range(3)] if hasattr(m, "transformer") else []
         self.cat = [dict(w0=f(s[0].weight), b0=f(s[0].bias), w2=f(s[2].weight), b2=f(s[2].bias)) for s in m.cat_layer]
 
-        self.head_names = [h for h in m.heads if "wh" not in h]
+        self.head_names = [h for h in m.heads if hasattr(m, h)]      # l3new has no 'wh' module (base_model.py:114-115)
         hw = torch.cat([getattr(m, h)[0].weight.detach().float() for h in self.head_names], 0)
         hb = torch.cat([getattr(m, h)[0].bias.detach().float() for h in self.head_names], 0)
         P["heads.0"] = PackedConv(hw, hb)
@@ -113,6 +104,18 @@ class Engine:
         for h in self.head_names:
             P["heads.2." + h] = PackedConv(getattr(m, h)[2].weight, getattr(m, h)[2].bias)
         self.P = P
+
+    def _pack_encoder(self, enc):
+        """One TransformerEncoder (its three layers alias ONE module, dla.py:788-789) -> flat weight dict."""
+        f = lambda t: t.detach().float().contiguous()          # noqa: E731
+        lay = enc.layers[0]
+        ca = lay.cross_attn
+        return dict(
+            wq=f(ca.w_q.weight), wkv=torch.cat([f(ca.w_k.weight), f(ca.w_v.weight)], 0).contiguous(),
+            fc_w=f(ca.fc.weight), fc_b=f(ca.fc.bias), pos=f(ca.pos_embed) if self.use_pos else None,
+            ln1=(f(lay.norm1.weight), f(lay.norm1.bias)), ln3=(f(lay.norm3.weight), f(lay.norm3.bias)),
+            w1=f(lay.linear1.weight), b1=f(lay.linear1.bias), w2=f(lay.linear2.weight), b2=f(lay.linear2.bias),
+            n=ca.n, C=ca.inp_dim, hid=ca.hid_dim)
 
     # ------------------------------------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32):
@@ -174,11 +177,16 @@ class Engine:
     def backbone(self, x, pre_img, pre_hm, repro_hm, after_level=None):
         """Both frames as one batch of 2B (previous first).  Returns the six level Views [2B, C_i, ...].
         ``after_level(i, view)`` is called as soon as level i's kernels are enqueued."""
-        B, _, H, W = x.shape
-        N = 2 * B
+        return self.backbone_frames(((pre_img, pre_hm), (x, repro_hm)), after_level)
+
+    def backbone_frames(self, frames, after_level=None):
+        """``frames`` = ((image, heat-map), ...) oldest first, current last: ONE batch of len(frames) * B images
+        through the shared-weight backbone."""
+        B, _, H, W = frames[-1][0].shape
+        N = len(frames) * B
         P = self.P
         s = self.buf("stem", (N, 16, H, W))
-        for half, (img, hm) in enumerate(((pre_img, pre_hm), (x, repro_hm))):
+        for half, (img, hm) in enumerate(frames):
             sl = slice(half * B, (half + 1) * B)
             if self.use_c16:                       # both 7x7 stems + BN + ReLU + sum in one kernel
                 ops.conv_c16(img, hm, P["stem.c16"], View(s[sl]))

@@ -10,9 +10,10 @@ from types import SimpleNamespace
 
 import torch
 
-from .networks.dla import DLAPlanAWindowL3New
+from .networks.dla import DLAPlanAWindowL3New, DLAPlanAWindowThree
 
-_network_factory = {"dlapawdl3new": DLAPlanAWindowL3New}
+_network_factory = {"dlapawdl3new": DLAPlanAWindowL3New,          # the live model (sgtapose/lib/model/model.py:19)
+                    "dlapawd3": DLAPlanAWindowThree}              # three-frame variant (model.py:18)
 
 DEFAULT_HEADS = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}        # opts_parallel.py:392-395
 
@@ -22,7 +23,7 @@ def default_opt(**over):
     o = dict(head_kernel=3, prior_bias=-4.6, dla_node="dcn", load_model="x", pre_img=True, pre_hm=True,
              ct_modify=False, num_classes=7, pos_embed=True, model_output_list=False,
              device=torch.device("cuda"), phase="PlanA_win", zero_tracking=False, flip_test=False,
-             out_thresh=0.001)       # max(track_thresh 0.001, out_thresh -1): opts_parallel.py:212, 263, 333
+             out_thresh=0.001, shared_ca=False)       # max(track_thresh 0.001, out_thresh -1): opts_parallel.py:212, 263, 333
     for i, ks in enumerate((12, 6, 3, 1, 1, 1), 1):
         o["k_list_%d" % i] = 1
         o["ks%d" % i] = ks
@@ -38,7 +39,7 @@ def create_model(arch, head, head_conv, opt=None):
     num_layers = int(arch[arch.find("_") + 1:]) if "_" in arch else 0
     name = arch[:arch.find("_")] if "_" in arch else arch
     if name not in _network_factory:
-        raise KeyError("architecture %r is outside the hot path; supported: dlapawdl3new_34" % arch)
+        raise KeyError("architecture %r is outside the hot path; supported: dlapawdl3new_34, dlapawd3_34" % arch)
     return _network_factory[name](num_layers, heads=head, head_convs=head_conv, opt=opt or default_opt())
 
 

@@ -251,3 +251,88 @@ class DLAPlanAWindowL3New(nn.Module):
     def _apply(self, fn, *a, **k):
         self._engine = None
         return super()._apply(fn, *a, **k)
+
+
+class DLAPlanAWindowThree(nn.Module):
+    """``DLA_PlanAWindow_Three`` ('dlapawd3', reference dla.py:1349-1456 over BaseModelPlanA_Three,
+    base_model.py:203-299): the current frame attends to the windows of TWO previous frames at levels 0-2 (one encoder
+    per frame unless ``opt.shared_ca``), levels 3-5 run cat_layer on every pixel.  Same constructor signature and
+    state_dict (690 / 564 keys) as the reference; SURVEY.md section 8f rank 2."""
+
+    scale_list = (4, 2, 1)
+
+    def __init__(self, num_layers, heads, head_convs, opt):
+        super().__init__()
+        if num_layers != 34:
+            raise ValueError("only dlapawd3_34 is built")
+        if getattr(opt, "dla_node", "dcn") != "dcn":
+            raise ValueError("only --dla_node dcn is supported")
+        self.opt = opt
+        self.heads = dict(heads)
+        self.num_stacks = 1
+        self.n_frames = 3
+        head_kernel = getattr(opt, "head_kernel", 3)
+        for name, classes in self.heads.items():          # BaseModelPlanA_Three keeps every head, 'wh' included
+            hc = head_convs[name]
+            if len(hc) != 1:
+                raise ValueError("head_conv must have exactly one hidden width (reference default [256])")
+            fc = _head(64, hc[0], classes, head_kernel)
+            if "hm" in name:
+                fc[-1].bias.data.fill_(opt.prior_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        nn.init.constant_(m.bias, 0)
+            setattr(self, name, fc)
+        self.first_level, self.last_level = 2, 5
+        self.base = DLA34()
+        ch = self.base.channels
+        self.dla_up = DLAUp(self.first_level, ch[self.first_level:], [2 ** i for i in range(len(ch) - self.first_level)])
+        self.ida_up = IDAUp(ch[self.first_level], ch[self.first_level:self.last_level],
+                            [2 ** i for i in range(self.last_level - self.first_level)])
+        self.K_list = [int(getattr(opt, "k_list_%d" % i)) for i in range(1, 4)]
+        self.kernel_list = [int(getattr(opt, "ks%d" % i)) for i in range(1, 4)]
+        if any(k != 1 for k in self.K_list):
+            raise ValueError("k_list_* must be 1 (the reference's inference setting)")
+        self.shared_ca = bool(getattr(opt, "shared_ca", False))
+        ncls = opt.num_classes
+
+        def encoders():
+            return nn.ModuleList([
+                Encoder(EncoderLayer(16 * 2 ** i, 4 * 2 ** i,
+                                     ncls * self.K_list[i] * (1 + 2 * (self.kernel_list[i] // 2)) ** 2), 3)
+                for i in range(3)])
+        if not self.shared_ca:
+            self.pprev_transformer = encoders()
+        self.prev_transformer = encoders()
+        self.cat_layer = nn.ModuleList([
+            nn.Sequential(nn.Linear(16 * 2 ** i * 3, 32 * 2 ** i * 3), nn.ReLU(), nn.Linear(32 * 2 ** i * 3, 16 * 2 ** i))
+            for i in range(6)])
+        self._engine = None
+
+    def forward(self, x, ppre_img=None, pre_img=None, ppre_hm=None, pre_hm=None, repro_hm=None,
+                ppre_hm_cls=None, pre_hm_cls=None, repro_hm_cls=None):
+        """base_model.py:267-299: list (num_stacks = 1) of {'hm','reg','wh','tracking'} logits."""
+        args = (ppre_img, pre_img, ppre_hm, pre_hm, repro_hm, ppre_hm_cls, pre_hm_cls, repro_hm_cls)
+        if any(t is None for t in args):
+            raise ValueError("the three-frame model needs all nine inputs")
+        if self.training:
+            raise RuntimeError("the HIP path is inference-only: call model.eval()")
+        return [self.engine().forward(x, *args)]
+
+    def engine(self):
+        if self._engine is None:
+            from ..engine_three import EngineThree
+            self._engine = EngineThree(self)
+        return self._engine
+
+    def invalidate(self):
+        self._engine = None
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)

@@ -127,6 +127,19 @@ def make_inputs(B, H, W, seed=317, n_kp=7, first_frame=False):
             "kp_pre": torch.from_numpy(kp_pre), "kp_cur": torch.from_numpy(kp_cur)}
 
 
+THREE_ARGS = ("x", "ppre_img", "pre_img", "ppre_hm", "pre_hm", "repro_hm", "ppre_hm_cls", "pre_hm_cls", "repro_hm_cls")
+
+
+def make_inputs_three(B, H, W, seed=317, n_kp=7):
+    """Inputs of the three-frame variant (BaseModelPlanA_Three.forward, base_model.py:267-269) in THREE_ARGS order:
+    the frame pair of ``make_inputs(seed)`` plus an older frame taken from ``make_inputs(seed + 1000)``."""
+    cur = make_inputs(B, H, W, seed, n_kp)
+    old = make_inputs(B, H, W, seed + 1000, n_kp)
+    return {"x": cur["x"], "ppre_img": old["pre_img"], "pre_img": cur["pre_img"], "ppre_hm": old["pre_hm"],
+            "pre_hm": cur["pre_hm"], "repro_hm": cur["repro_hm"], "ppre_hm_cls": old["pre_hm_cls"],
+            "pre_hm_cls": cur["pre_hm_cls"], "repro_hm_cls": cur["repro_hm_cls"]}
+
+
 def peaked_heatmaps(B, h, w, seed=317, n_kp=7, amp=0.9, floor=0.002):
     """Post-sigmoid-like heat-maps with one Gaussian blob (sigma 2) per class at a sub-pixel
     centre -- used for decode / keypoint parity since random-init logits are flat."""

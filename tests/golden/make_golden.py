@@ -27,8 +27,8 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, REPO)
 
-from ref_import import build_reference_model, load_reference  # noqa: E402
-from sgtapose_amd.synthetic import fill_state_dict_, make_inputs  # noqa: E402
+from ref_import import build_reference_model, build_reference_model_three, load_reference  # noqa: E402
+from sgtapose_amd.synthetic import THREE_ARGS, fill_state_dict_, make_inputs, make_inputs_three  # noqa: E402
 import cases  # noqa: E402
 
 torch.set_num_threads(1)
@@ -201,7 +201,29 @@ def prepost_ops():
     save("prepost_ops.npz", **arrs)
 
 
+def three_frames():
+    """DLA_PlanAWindow_Three: state_dict keys + head logits of the reference model."""
+    for shared, tag in ((False, ""), (True, "_shared")):
+        model, _ = build_reference_model_three(shared)
+        sd = model.state_dict()
+        keys = [[k, list(v.shape)] for k, v in sd.items()]
+        with open(os.path.join(HERE, "model_keys_three%s.json" % tag), "w") as f:
+            json.dump({"arch": "dlapawd3_34", "shared_ca": shared, "n_keys": len(keys), "keys": keys}, f)
+        fill_state_dict_(sd, seed=0)
+        for name, B, H, W, seed in (("128", 2, 128, 128, 417), ("96x160", 1, 96, 160, 418)):
+            if shared and name != "128":
+                continue
+            inp = make_inputs_three(B, H, W, seed=seed)
+            with torch.no_grad():
+                out = model(*[inp[k] for k in THREE_ARGS])[-1]
+            save("fullnet_three%s_%s.npz" % (tag, name), meta=np.array([B, H, W, seed, int(shared)]),
+                 **{k: v for k, v in out.items()})
+
+
 def main():
+    if "--three-only" in sys.argv:
+        three_frames()
+        return
     if "--prepost-only" in sys.argv:
         prepost_ops()
         return
@@ -216,6 +238,7 @@ def main():
     encoder_ops(model)
     decode_ops()
     prepost_ops()
+    three_frames()
     fullnet(model, "128", 2, 128, 128, 317, extra=True)
     fullnet(model, "128_first", 1, 128, 128, 318, first_frame=True)
     fullnet(model, "96x160", 1, 96, 160, 319)

@@ -92,3 +92,14 @@ def build_reference_model(opt=None):
     with contextlib.redirect_stdout(io.StringIO()):      # the constructors print banners
         model = ref.dla.DLA_PlanAWindow_l3new(34, dict(HEADS), dict(HEAD_CONV), opt)
     return model.eval(), opt
+
+
+def build_reference_model_three(shared_ca=False):
+    """DLA_PlanAWindow_Three ('dlapawd3', sgtapose/lib/model/model.py:18): two previous frames."""
+    ref = load_reference()
+    opt = reference_opt(shared_ca=shared_ca)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref.dla.DLA_PlanAWindow_Three(34, dict(HEADS), dict(HEAD_CONV), opt)
+    return model.eval(), opt

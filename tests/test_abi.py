@@ -124,3 +124,18 @@ def test_dcn_signature_and_guards():
     assert float(d.conv_offset_mask.weight.abs().sum()) == 0
     with pytest.raises(ValueError):
         DCN(64, 32, kernel_size=3, stride=2, padding=1)
+
+
+def test_three_frame_state_dict_matches_reference():
+    """dlapawd3_34 mirror: key order, shapes and layer aliasing of DLA_PlanAWindow_Three (both shared_ca settings)."""
+    import torch
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from util import model_keys
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    for shared, kf in ((False, "model_keys_three.json"), (True, "model_keys_three_shared.json")):
+        m = create_model("dlapawd3_34", heads, default_head_conv(heads), default_opt(shared_ca=shared, device=torch.device("cpu")))
+        sd = m.state_dict()
+        assert [[k, list(v.shape)] for k, v in sd.items()] == model_keys(kf)
+        a, b = sd["prev_transformer.0.layers.0.linear1.weight"], sd["prev_transformer.0.layers.2.linear1.weight"]
+        assert a.data_ptr() == b.data_ptr()
+        assert ("pprev_transformer.0.layers.0.linear1.weight" in sd) == (not shared)

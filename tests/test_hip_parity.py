@@ -582,3 +582,24 @@ def test_fullnet_random_sizes_match_oracle(model, B, H, W, seed):
     for k in ("hm", "reg", "tracking"):
         err = float((out[k].cpu() - ref[k]).abs().max())
         assert out[k].shape == ref[k].shape and err < 1e-3, (k, err)
+
+
+# ---- the three-frame variant ----------------------------------------------------------
+@pytest.mark.parametrize("tag", ["128", "96x160", "shared_128"])
+def test_three_frame_model_matches_reference(tag):
+    """dlapawd3_34 on the HIP path against DLA_PlanAWindow_Three of the reference (golden head logits, incl. 'wh')."""
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from sgtapose_amd.synthetic import THREE_ARGS, make_inputs_three
+    g = golden("fullnet_three_%s.npz" % tag)
+    B, H, W, seed, shared = [int(v) for v in g["meta"]]
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    m = create_model("dlapawd3_34", heads, default_head_conv(heads), default_opt(shared_ca=bool(shared)))
+    m.load_state_dict(golden_state_dict(keys="model_keys_three_shared.json" if shared else "model_keys_three.json"),
+                      strict=True)
+    m = m.to(DEV).eval()
+    inp = make_inputs_three(B, H, W, seed=seed)
+    out = m(*[inp[k].to(DEV) for k in THREE_ARGS])[-1]
+    assert sorted(out) == ["hm", "reg", "tracking", "wh"]
+    for k in out:
+        err = float((out[k].cpu() - t(g[k])).abs().max())
+        assert out[k].shape == g[k].shape and err < 1e-3, (k, err)

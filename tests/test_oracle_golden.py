@@ -169,3 +169,17 @@ def test_prior_rendering_and_post_process_match_reference():
                 assert np.array_equal(np.asarray(item[k], np.float32), g["pp_" + k][b, j]), (b, j, k)
         assert np.array_equal(valid, g["pp_valid"][b])
         assert np.array_equal(op.get_final_kps(out[b], K), g["final_kps"][b])
+
+
+@pytest.mark.parametrize("tag", ["128", "96x160", "shared_128"])
+def test_three_frame_variant_matches_reference(tag):
+    """oracle.plan_a_window_three_forward against DLA_PlanAWindow_Three of the reference."""
+    from sgtapose_amd.synthetic import THREE_ARGS, make_inputs_three
+    g = golden("fullnet_three_%s.npz" % tag)
+    B, H, W, seed, shared = [int(v) for v in g["meta"]]
+    sd = golden_state_dict(keys="model_keys_three_shared.json" if shared else "model_keys_three.json")
+    inp = make_inputs_three(B, H, W, seed=seed)
+    out = oracle.plan_a_window_three_forward(sd, *[inp[k] for k in THREE_ARGS], shared_ca=bool(shared))
+    assert sorted(out) == ["hm", "reg", "tracking", "wh"]
+    for k in out:
+        assert torch.allclose(out[k], t(g[k]), atol=2e-5), (k, float((out[k] - t(g[k])).abs().max()))

@@ -13,21 +13,21 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name))
 
 
-def model_keys():
-    with open(os.path.join(GOLDEN, "model_keys.json")) as f:
+def model_keys(name="model_keys.json"):
+    with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)["keys"]
 
 
 _SD_CACHE = {}
 
 
-def golden_state_dict(seed=0):
-    """The reference model's 560 state_dict entries, rebuilt from (seed, name, shape) alone."""
+def golden_state_dict(seed=0, keys="model_keys.json"):
+    """The reference model's state_dict entries (560 for dlapawdl3new_34), rebuilt from (seed, name, shape) alone."""
     from sgtapose_amd.synthetic import fill_state_dict_
-    if seed not in _SD_CACHE:
+    if (seed, keys) not in _SD_CACHE:
         sd = {}
-        for k, shape in model_keys():
+        for k, shape in model_keys(keys):
             dt = torch.long if k.endswith("num_batches_tracked") else torch.float32
             sd[k] = torch.zeros(shape, dtype=dt)
-        _SD_CACHE[seed] = fill_state_dict_(sd, seed)
-    return _SD_CACHE[seed]
+        _SD_CACHE[(seed, keys)] = fill_state_dict_(sd, seed)
+    return _SD_CACHE[(seed, keys)]
