@@ -177,6 +177,13 @@ int sgta_linear_f32(const float* x, int ldx, const float* w, const float* bias, 
                     int ldr, const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M,
                     int N, int K, int relu, sgta_stream_t stream);
 
+/* Same operator with a caller-owned workspace (ws_floats floats, may be NULL / 0): for the few-hundred-token
+ * cat_layer products of levels 3-5 (dla.py:1537-1543: M = B*7 rows, K up to 2048) K is split over work-groups
+ * and the partial sums are added in split order by a second kernel (deterministic).  4.2 M floats always suffice. */
+int sgta_linear_ws_f32(const float* x, int ldx, const float* w, const float* bias, const float* res,
+                       int ldr, const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M,
+                       int N, int K, int relu, float* ws, long ws_floats, sgta_stream_t stream);
+
 /* out[b,i,h*d:(h+1)*d] = softmax_j(q_i.k_j/sqrt(d) + pos_embed[h,i,j]) . v_j  per head
  * (MHCA_ein.forward, dla.py:874-885); q/k/v/out row-major [B*n, ld*]; pos_embed [n_heads,n,n] or NULL;
  * head_dim in {4,8,16}. */

@@ -17,6 +17,7 @@ struct LinArgs {
   const float* gamma; const float* beta;   // LayerNorm affine (LN variant)
   float* y; int ldy;
   int M, N, K, relu;
+  float* ws; int cps;           // split-K: partial sums [gridDim.z][M][N], BK-chunks per split (0 = no split)
 };
 
 template <bool LN>
@@ -59,13 +60,17 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-  const int nchunks = a.K / BK;
-  load(0);
-  store(0);
+  // split-K (token counts of a few hundred rows leave the 128 x 64 tiles on a handful of CUs, each walking the
+  // whole K behind one global-load latency per 16-deep chunk): blockIdx.z owns chunks [kc0, kc1)
+  const int nall = a.K / BK;
+  const int kc0 = a.cps ? blockIdx.z * a.cps : 0;
+  const int kc1 = a.cps ? (kc0 + a.cps < nall ? kc0 + a.cps : nall) : nall;
+  load(kc0);
+  store(kc0 & 1);
   __syncthreads();
-  for (int kc = 0; kc < nchunks; ++kc) {
+  for (int kc = kc0; kc < kc1; ++kc) {
     const int buf = kc & 1;
-    const bool more = kc + 1 < nchunks;
+    const bool more = kc + 1 < kc1;
     if (more) load(kc + 1);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
@@ -80,6 +85,20 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   }
 
   // epilogue: row m = m0 + wave*32 + (r&3) + 8*(r>>2) + 4*lh ; col n = n0 + j*32 + l31
+  if (a.cps) {                                       // raw partial sums; linear_splitk_reduce_kernel finishes
+    float* wsz = a.ws + (long)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + j * 32 + l31;
+        if (n < a.N) wsz[(long)m * a.N + n] = acc[j][r];
+      }
+    }
+    return;
+  }
   float bj[2], gj[2], tj[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -125,18 +144,74 @@ __global__ __launch_bounds__(256) void linear_kernel(LinArgs a) {
   }
 }
 
+// y = relu?(sum_z ws[z] + bias) + res, summed in split order (deterministic); one thread = 4 features of a row
+__global__ __launch_bounds__(256) void linear_splitk_reduce_kernel(const float* __restrict__ ws, int S,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ res, int ldr,
+                                                                   float* __restrict__ y, int ldy, int M, int N,
+                                                                   int relu) {
+  const int nq = N >> 2;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)M * nq) return;
+  const int m = (int)(i / nq), n = (int)(i - (long)m * nq) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + (long)m * N + n);
+  for (int z = 1; z < S; ++z) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(ws + ((long)z * M + m) * N + n);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += t[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float t = v[q] + (bias ? bias[n + q] : 0.0f);
+    if (relu) t = fmaxf(t, 0.0f);
+    if (res) t += res[(long)m * ldr + n + q];
+    y[(long)m * ldy + n + q] = t;
+  }
+}
+
+extern "C" int sgta_linear_ws_f32(const float* x, int ldx, const float* w, const float* bias, const float* res,
+                                  int ldr, const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M,
+                                  int N, int K, int relu, float* ws, long ws_floats, hipStream_t st);
+
 extern "C" int sgta_linear_f32(const float* x, int ldx, const float* w, const float* bias,
                                const float* res, int ldr, const float* ln_gamma, const float* ln_beta,
                                float* y, int ldy, int M, int N, int K, int relu, hipStream_t st) {
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || (K % 16) || (ldx % 4)) return SGTA_EBADARG;
   if ((ln_gamma != nullptr) != (ln_beta != nullptr)) return SGTA_EBADARG;
   if (ln_gamma && N > 64) return SGTA_EBADARG;     // fused LayerNorm needs the whole row in one tile
-  LinArgs a{x, ldx, w, bias, res, ldr, ln_gamma, ln_beta, y, ldy, M, N, K, relu};
+  return sgta_linear_ws_f32(x, ldx, w, bias, res, ldr, ln_gamma, ln_beta, y, ldy, M, N, K, relu, nullptr, 0, st);
+}
+
+// Same operator with a caller-owned workspace of ws_floats floats: when the 128 x 64 tiles alone would leave most
+// CUs idle (few hundred tokens) and the workspace is large enough, K is split over blockIdx.z and a second kernel
+// sums the partials in split order and applies the epilogue.  No LayerNorm variant (its rows fit one tile: large M).
+extern "C" int sgta_linear_ws_f32(const float* x, int ldx, const float* w, const float* bias, const float* res,
+                                  int ldr, const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M,
+                                  int N, int K, int relu, float* ws, long ws_floats, hipStream_t st) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || (K % 16) || (ldx % 4)) return SGTA_EBADARG;
+  if ((ln_gamma != nullptr) != (ln_beta != nullptr)) return SGTA_EBADARG;
+  if (ln_gamma && N > 64) return SGTA_EBADARG;     // fused LayerNorm needs the whole row in one tile
+  LinArgs a{x, ldx, w, bias, res, ldr, ln_gamma, ln_beta, y, ldy, M, N, K, relu, nullptr, 0};
   dim3 grid((M + 127) / 128, (N + 63) / 64);
-  if (ln_gamma)
-    hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, st, a);
-  else
+  const int tiles = grid.x * grid.y, nchunks = K / 16;
+  int S = 1;
+  if (ws && !ln_gamma && N % 4 == 0 && ldy % 4 == 0 && tiles < 128) {
+    while (S < 32 && tiles * S < 256 && nchunks / (S * 2) >= 4) S *= 2;     // >= 4 chunks per split
+    while (S > 1 && (long)S * M * N > ws_floats) S /= 2;
+  }
+  if (S > 1) {
+    a.ws = ws;
+    a.cps = (nchunks + S - 1) / S;
+    grid.z = (nchunks + a.cps - 1) / a.cps;
     hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), 0, st, a);
+    const long nthreads = (long)M * (N / 4);
+    hipLaunchKernelGGL(linear_splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, (int)grid.z, bias, res, ldr, y, ldy, M, N, relu);
+  } else if (ln_gamma) {
+    hipLaunchKernelGGL(linear_kernel<true>, grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(linear_kernel<false>, grid, dim3(256), 0, st, a);
+  }
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

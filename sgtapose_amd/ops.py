@@ -339,6 +339,7 @@ def _splitk_ws(dev, nfloats):
     return t
 
 
+LINEAR_SPLITK_MAX_ROWS = 1024   # token GEMMs with at most this many rows may split K (0 disables)
 USE_WINO4 = True               # F(4x4,3x3) where the map fills its 64-tile blocks (else F(2x2,3x3))
 WINO4_MIN_FILL = 0.7           # minimum useful fraction of the 4x4-tile blocks
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)
@@ -494,9 +495,14 @@ def linear(x, w, bias, out, relu=False, res=None, ln=None, K=None):
     assert x.stride(-1) == 1 and out.stride(-1) == 1 and w.is_contiguous()
     g, bt = (ln[0].data_ptr(), ln[1].data_ptr()) if ln is not None else (None, None)
     rp, ldr = (res.data_ptr(), res.stride(0)) if res is not None else (None, 0)
-    _lib.call("sgta_linear_f32", x.data_ptr(), x.stride(0), w.data_ptr(),
+    ws, nws = None, 0
+    if ln is None and M <= LINEAR_SPLITK_MAX_ROWS and K >= 256:
+        # few-hundred-token products (cat_layer of levels 3-5): split-K over work-groups, see sgta_linear_ws_f32
+        nws = min(32 * M * N, 4 << 20)
+        ws = _splitk_ws(x.device, nws)
+    _lib.call("sgta_linear_ws_f32", x.data_ptr(), x.stride(0), w.data_ptr(),
               None if bias is None else bias.data_ptr(), rp, ldr, g, bt, out.data_ptr(), out.stride(0),
-              M, N, K, int(relu), _stream())
+              M, N, K, int(relu), None if ws is None else ws.data_ptr(), nws, _stream())
     return out
 
 

@@ -298,6 +298,30 @@ def test_linear_with_relu_residual_layernorm(ops):
             assert torch.allclose(out.cpu(), F.layer_norm(ref + r, (N,), gm, bt, 1e-5), atol=5e-5, rtol=1e-5)
 
 
+def test_linear_split_k_matches_direct_and_is_deterministic(ops):
+    """The few-hundred-token products of cat_layer (dla.py:1537-1543) split K over work-groups: same results as the
+    un-split kernel within fp32 summation-order noise, bit-identical from run to run, residual / ReLU after the sum."""
+    g = torch.Generator().manual_seed(19)
+    for (M, N, K) in ((224, 2048, 1024), (224, 512, 2048), (7, 128, 512), (231, 1024, 512), (224, 256, 1024)):
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        ref = F.relu(F.linear(x, w, b)) + r
+        xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+        out = [torch.empty(M, N, device=DEV) for _ in range(3)]
+        ops.linear(xd, wd, bd, out[0], relu=True, res=rd)
+        ops.linear(xd, wd, bd, out[1], relu=True, res=rd)
+        keep, ops.LINEAR_SPLITK_MAX_ROWS = ops.LINEAR_SPLITK_MAX_ROWS, 0
+        try:
+            ops.linear(xd, wd, bd, out[2], relu=True, res=rd)
+        finally:
+            ops.LINEAR_SPLITK_MAX_ROWS = keep
+        assert torch.equal(out[0], out[1])
+        assert torch.allclose(out[0].cpu(), ref, atol=3e-5, rtol=1e-5)
+        assert torch.allclose(out[2].cpu(), ref, atol=3e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("i", [2, 1, 0])
 def test_attention_and_encoder_match_reference(ops, model, i):
     g = golden("encoder_ops.npz")
