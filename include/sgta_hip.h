@@ -202,6 +202,18 @@ int sgta_peaks_decode(const float* hm, const float* reg, const float* tracking, 
                       float* regs, float* trks, int* npeaks, int B, int K, int H, int W,
                       sgta_stream_t stream);
 
+/* The same decode plus the derived entries of dream_generic_decode's dictionary (decode.py:296-312), so that no
+ * element-wise glue follows: cts int64 [B,K,2] = (xs, ys); cts_wreg f32 [B,K,2] = float32(cts) + regs; regs_rel f32
+ * [B,K,2] = cts_wreg - float32(cts) (each may be NULL; the last two need reg).  three_pass != 0 forces the
+ * three-kernel form (separable passes through ws_tmp, one work-group per map); by default both Gaussian passes, the
+ * local-maximum test and the candidate selection of 24 rows of a map run in one work-group (LDS tile), and the tiles
+ * of a map are merged by a second kernel -- identical results (same arithmetic per value, order-free selection).
+ * ws_tmp must be 8-byte aligned (it also carries the per-tile candidates); ws_filt receives the filtered maps. */
+int sgta_peaks_decode_full(const float* hm, const float* reg, const float* tracking, const double* gauss_w13,
+                           float* ws_tmp, float* ws_filt, float* scores, long long* xs, long long* ys,
+                           float* regs, float* trks, int* npeaks, long long* cts, float* cts_wreg,
+                           float* regs_rel, int B, int K, int H, int W, int three_pass, sgta_stream_t stream);
+
 /* SoftArgmaxPavlo.forward (sgtapose/spatial_softmax.py:24-95): out_xy f32 [B,K,2] = (E[col], E[row]). */
 int sgta_softargmax(const float* hm, float* out_xy, int B, int K, int H, int W, float beta,
                     float size_mult, sgta_stream_t stream);

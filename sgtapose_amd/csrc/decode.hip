@@ -67,12 +67,19 @@ __device__ __forceinline__ void cand_insert(Cand& c0, Cand& c1, const Cand& n) {
   else if (cand_before(n, c1)) { c1 = n; }
 }
 
+extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const float* tracking,
+                                      const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
+                                      long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
+                                      long long* cts, float* cts_wreg, float* regs_rel, int B, int K, int H, int W,
+                                      int three_pass, hipStream_t st);
+
 // one work-group per (b, class) map
 __global__ __launch_bounds__(256) void peaks_select_kernel(
     const float* __restrict__ hm, const float* __restrict__ gf, const float* __restrict__ reg,
     const float* __restrict__ trk, float* __restrict__ scores, long long* __restrict__ xs,
     long long* __restrict__ ys, float* __restrict__ regs, float* __restrict__ trks,
-    int* __restrict__ npeaks, int K, int H, int W) {
+    int* __restrict__ npeaks, long long* __restrict__ cts, float* __restrict__ cts_wreg,
+    float* __restrict__ regs_rel, int K, int H, int W) {
   const int map = blockIdx.x, b = map / K;
   const int HW = H * W;
   const float* ori = hm + (long)map * HW;
@@ -131,25 +138,231 @@ __global__ __launch_bounds__(256) void peaks_select_kernel(
     scores[map] = sc; xs[map] = xi; ys[map] = yi;
     if (npeaks) npeaks[map] = n;
     const long ind = yi * W + xi;
+    float rg[2] = {0.0f, 0.0f};
     for (int c = 0; c < 2; ++c) {
-      if (reg) regs[map * 2 + c] = reg[((long)b * 2 + c) * HW + ind];
+      if (reg) { rg[c] = reg[((long)b * 2 + c) * HW + ind]; regs[map * 2 + c] = rg[c]; }
       if (trk) trks[map * 2 + c] = trk[((long)b * 2 + c) * HW + ind];
     }
+    if (cts) { cts[map * 2] = xi; cts[map * 2 + 1] = yi; }
+    if (cts_wreg && reg) {
+      const float fx = (float)xi, fy = (float)yi;
+      const float wx = __fadd_rn(fx, rg[0]), wy = __fadd_rn(fy, rg[1]);
+      cts_wreg[map * 2] = wx; cts_wreg[map * 2 + 1] = wy;
+      if (regs_rel) { regs_rel[map * 2] = __fsub_rn(wx, fx); regs_rel[map * 2 + 1] = __fsub_rn(wy, fy); }
+    }
   }
+}
+
+// ---- fused form: both Gaussian passes, the local-maximum test and the per-tile candidate selection in ONE kernel ---
+// A work-group owns TH rows of one map: it stages the TH + 26 input rows it needs (row indices already reflected),
+// runs the vertical pass for TH + 2 rows (one halo row each side for the 4-neighbour test) into LDS as float32 --
+// scipy stores float32 after each axis --, extends those rows by 12 reflected columns each side, runs the horizontal
+// pass into LDS, writes its TH filtered rows (ws_filt; kept as an output because the filter is pinned bit-exact
+// against scipy by the tests), and reduces the tile's local maxima to its two first candidates + their count.
+// peaks_merge_kernel then merges the tiles of a map (the first two of a union are among the first two of its parts).
+// Arithmetic per output is exactly gauss1d_kernel's; the three-kernel form above stays as the fall-back for maps too
+// wide for the LDS tile and as the cross-check in tests.
+#define GP_TH 24
+struct TileCands { Cand c0, c1; int cnt, pad; };
+
+__global__ __launch_bounds__(256) void gauss_peaks_kernel(const float* __restrict__ hm, float* __restrict__ filt,
+                                                         const double* __restrict__ w, TileCands* __restrict__ tc,
+                                                         int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  const int map = blockIdx.y, tile = blockIdx.x, y0 = tile * GP_TH;
+  const int WP = W + 2 * GRADIUS;
+  float* sin = gsm;                                   // [GP_TH + 26][W]   input rows y0 - 13 + k (reflected)
+  float* stmp = sin + (GP_TH + 26) * W;               // [GP_TH + 2][WP]   vertical pass, rows y0 - 1 + k
+  float* sf = stmp + (GP_TH + 2) * WP;                // [GP_TH + 2][W]    filtered rows y0 - 1 + k
+  const float* src = hm + (long)map * H * W;
+  double wr[GRADIUS + 1];
+#pragma unroll
+  for (int j = 0; j <= GRADIUS; ++j) wr[j] = w[j];
+  for (int e = threadIdx.x; e < (GP_TH + 26) * W; e += 256) {
+    const int k = e / W, x = e - k * W;
+    sin[e] = src[(long)reflect_idx(y0 - 13 + k, H) * W + x];
+  }
+  __syncthreads();
+  // vertical pass: output row yy = y0 - 1 + k reads input rows yy - 12 .. yy + 12 = LDS rows k .. k + 24
+  for (int e = threadIdx.x; e < (GP_TH + 2) * W; e += 256) {
+    const int k = e / W, x = e - k * W;
+    const float* col = sin + (k + GRADIUS) * W + x;   // centre row
+    double acc = __dmul_rn((double)col[0], wr[GRADIUS]);
+#pragma unroll
+    for (int j = -GRADIUS; j < 0; ++j)
+      acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)col[j * W], (double)col[-j * W]), wr[GRADIUS + j]));
+    stmp[k * WP + GRADIUS + x] = (float)acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < (GP_TH + 2) * 2 * GRADIUS; e += 256) {     // reflected borders of every row
+    const int k = e / (2 * GRADIUS), i = e - k * (2 * GRADIUS);
+    const int x = i < GRADIUS ? i - GRADIUS : W + (i - GRADIUS);
+    stmp[k * WP + GRADIUS + x] = stmp[k * WP + GRADIUS + reflect_idx(x, W)];
+  }
+  __syncthreads();
+  float* out = filt + (long)map * H * W;
+  for (int e = threadIdx.x; e < (GP_TH + 2) * W; e += 256) {
+    const int k = e / W, x = e - k * W;
+    const float* row = stmp + k * WP + GRADIUS + x;
+    double acc = __dmul_rn((double)row[0], wr[GRADIUS]);
+#pragma unroll
+    for (int j = -GRADIUS; j < 0; ++j)
+      acc = __dadd_rn(acc, __dmul_rn(__dadd_rn((double)row[j], (double)row[-j]), wr[GRADIUS + j]));
+    const float v = (float)acc;
+    sf[e] = v;
+    const int yy = y0 - 1 + k;
+    if (k >= 1 && k <= GP_TH && yy < H) out[(long)yy * W + x] = v;
+  }
+  __syncthreads();
+  // local maxima of this tile's rows (peaks_select_kernel's test and centroid, rows beyond the map count as 0)
+  const float* ori = src;
+  Cand c0{0, 0, 0, -1}, c1{0, 0, 0, -1};
+  int cnt = 0;
+  for (int e = threadIdx.x; e < GP_TH * W; e += 256) {
+    const int k = e / W + 1, x = e - (k - 1) * W, y = y0 - 1 + k;
+    if (y >= H) break;
+    const float* g = sf + k * W + x;
+    const float v = g[0];
+    const float up = y > 0 ? g[-W] : 0.0f, dn = y < H - 1 ? g[W] : 0.0f;
+    const float lf = x > 0 ? g[-1] : 0.0f, rt = x < W - 1 ? g[1] : 0.0f;
+    if (!(v >= up && v >= dn && v >= lf && v >= rt && v > 0.01f)) continue;
+    ++cnt;
+    double sw = 0.0, sx = 0.0, sy = 0.0;
+    for (int dx = -2; dx <= 2; ++dx)              // numpy flattening: dx is the slow index
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const double wv = (double)ori[yy * W + xx];
+        sw += wv;
+        sx += __dmul_rn((double)xx, wv);
+        sy += __dmul_rn((double)yy, wv);
+      }
+    Cand n;
+    if (sw == 0.0) { n.cx = x + 0.4395; n.cy = y + 0.4395; }
+    else { n.cx = sx / sw + 0.4395; n.cy = sy / sw + 0.4395; }
+    n.idx = y * W + x;
+    n.score = ori[n.idx];
+    cand_insert(c0, c1, n);
+  }
+  __syncthreads();                                  // the tile arrays are dead: reuse the LDS for the reduction
+  Cand* s0 = reinterpret_cast<Cand*>(gsm);
+  Cand* s1 = s0 + 256;
+  int* scnt = reinterpret_cast<int*>(s1 + 256);
+  s0[threadIdx.x] = c0; s1[threadIdx.x] = c1; scnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      Cand a0 = s0[threadIdx.x], a1 = s1[threadIdx.x];
+      cand_insert(a0, a1, s0[threadIdx.x + o]);
+      cand_insert(a0, a1, s1[threadIdx.x + o]);
+      s0[threadIdx.x] = a0; s1[threadIdx.x] = a1;
+      scnt[threadIdx.x] += scnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    TileCands t;
+    t.c0 = s0[0]; t.c1 = s1[0]; t.cnt = scnt[0]; t.pad = 0;
+    tc[(long)map * gridDim.x + tile] = t;
+  }
+}
+
+// one thread per map: merge the tiles, apply the reference's multi-peak rule, gather reg / tracking, and emit the
+// derived entries of the decode dictionary (decode.py:296-312: cts, cts_wreg = int64 + float32 -> float32,
+// regs = cts_wreg - cts in float32) so that no element-wise glue kernels follow
+__global__ __launch_bounds__(64) void peaks_merge_kernel(
+    const TileCands* __restrict__ tc, int ntiles, const float* __restrict__ hm, const float* __restrict__ reg,
+    const float* __restrict__ trk, float* __restrict__ scores, long long* __restrict__ xs, long long* __restrict__ ys,
+    float* __restrict__ regs, float* __restrict__ trks, int* __restrict__ npeaks, long long* __restrict__ cts,
+    float* __restrict__ cts_wreg, float* __restrict__ regs_rel, int nmaps, int K, int H, int W) {
+  const int map = blockIdx.x * 64 + threadIdx.x;
+  if (map >= nmaps) return;
+  const int b = map / K, HW = H * W;
+  Cand best{0, 0, 0, -1}, second{0, 0, 0, -1};
+  int n = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const TileCands v = tc[(long)map * ntiles + t];
+    cand_insert(best, second, v.c0);
+    cand_insert(best, second, v.c1);
+    n += v.cnt;
+  }
+  const float* ori = hm + (long)map * HW;
+  const bool have = (n == 1) || (n > 1 && (best.score - second.score) >= 0.25f);
+  long long xi = 0, yi = 0;
+  float sc = -1.0f;
+  if (have) {
+    xi = (long long)best.cx;                     // int(): truncation
+    yi = (long long)best.cy;
+    sc = ori[yi * W + xi];
+  }
+  scores[map] = sc; xs[map] = xi; ys[map] = yi;
+  if (npeaks) npeaks[map] = n;
+  const long ind = yi * W + xi;
+  float rg[2] = {0.0f, 0.0f};
+  for (int c = 0; c < 2; ++c) {
+    if (reg) { rg[c] = reg[((long)b * 2 + c) * HW + ind]; regs[map * 2 + c] = rg[c]; }
+    if (trk) trks[map * 2 + c] = trk[((long)b * 2 + c) * HW + ind];
+  }
+  if (cts) { cts[map * 2] = xi; cts[map * 2 + 1] = yi; }
+  if (cts_wreg && reg) {
+    const float fx = (float)xi, fy = (float)yi;
+    const float wx = __fadd_rn(fx, rg[0]), wy = __fadd_rn(fy, rg[1]);
+    cts_wreg[map * 2] = wx; cts_wreg[map * 2 + 1] = wy;
+    if (regs_rel) { regs_rel[map * 2] = __fsub_rn(wx, fx); regs_rel[map * 2 + 1] = __fsub_rn(wy, fy); }
+  }
+}
+
+static bool gauss_peaks_fits(int W, size_t* bytes) {
+  const size_t fl = (size_t)(GP_TH + 26) * W + (size_t)(GP_TH + 2) * (W + 2 * GRADIUS) + (size_t)(GP_TH + 2) * W;
+  size_t b = fl * sizeof(float);
+  const size_t red = 512 * sizeof(Cand) + 256 * sizeof(int);
+  if (b < red) b = red;
+  *bytes = b;
+  return b <= 150 * 1024;
 }
 
 extern "C" int sgta_peaks_decode(const float* hm, const float* reg, const float* tracking,
                                  const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
                                  long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
                                  int B, int K, int H, int W, hipStream_t st) {
+  return sgta_peaks_decode_full(hm, reg, tracking, gauss_w13, ws_tmp, ws_filt, scores, xs, ys, regs, trks, npeaks,
+                                nullptr, nullptr, nullptr, B, K, H, W, 0, st);
+}
+
+extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const float* tracking,
+                                      const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
+                                      long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
+                                      long long* cts, float* cts_wreg, float* regs_rel, int B, int K, int H, int W,
+                                      int three_pass, hipStream_t st) {
   if (!hm || !gauss_w13 || !ws_tmp || !ws_filt || !scores || !xs || !ys) return SGTA_EBADARG;
   if (B <= 0 || K <= 0 || H <= 0 || W <= 0 || (reg && !regs) || (tracking && !trks)) return SGTA_EBADARG;
-  long total = (long)B * K * H * W;
+  if ((cts_wreg || regs_rel) && !reg) return SGTA_EBADARG;
+  const long total = (long)B * K * H * W;
+  const int ntiles = (H + GP_TH - 1) / GP_TH;
+  size_t lds = 0;
+  // the tile candidates live in ws_tmp (hm-sized float workspace): it must hold them and be 8-byte aligned
+  const bool fused = !three_pass && gauss_peaks_fits(W, &lds) && ((uintptr_t)ws_tmp & 7) == 0 &&
+                     (size_t)ntiles * sizeof(TileCands) <= (size_t)H * W * sizeof(float);
+  if (fused) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_peaks_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+        return SGTA_EBADARG;
+      attr_set = true;
+    }
+    TileCands* tc = reinterpret_cast<TileCands*>(ws_tmp);
+    hipLaunchKernelGGL(gauss_peaks_kernel, dim3(ntiles, B * K), dim3(256), lds, st, hm, ws_filt, gauss_w13, tc, H, W);
+    hipLaunchKernelGGL(peaks_merge_kernel, dim3((B * K + 63) / 64), dim3(64), 0, st, (const TileCands*)tc, ntiles, hm,
+                       reg, tracking, scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, B * K, K, H, W);
+    SGTA_LAUNCH_CHECK();
+    return SGTA_OK;
+  }
   int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(gauss1d_kernel<0>, dim3(grid), dim3(256), 0, st, hm, ws_tmp, gauss_w13, H, W, total);
   hipLaunchKernelGGL(gauss1d_kernel<1>, dim3(grid), dim3(256), 0, st, (const float*)ws_tmp, ws_filt, gauss_w13, H, W, total);
   hipLaunchKernelGGL(peaks_select_kernel, dim3(B * K), dim3(256), 0, st, hm, (const float*)ws_filt, reg, tracking,
-                     scores, xs, ys, regs, trks, npeaks, K, H, W);
+                     scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, K, H, W);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

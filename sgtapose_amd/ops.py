@@ -529,8 +529,9 @@ def gauss_taps(device):
     return _GAUSS[key]
 
 
-def peaks_decode(hm, reg=None, tracking=None, ws=None):
-    """hm [B,K,H,W] post-sigmoid.  Returns dict(scores, xs, ys, regs, trks, npeaks) of device tensors."""
+def peaks_decode(hm, reg=None, tracking=None, ws=None, three_pass=False):
+    """hm [B,K,H,W] post-sigmoid.  Returns dict(scores, xs, ys, regs, trks, npeaks, cts[, cts_wreg, regs_rel]) of
+    device tensors (the last two only with ``reg``).  ``three_pass`` forces the un-fused kernels (cross-check)."""
     _req(hm)
     B, K, H, W = hm.shape
     dev = hm.device
@@ -542,12 +543,18 @@ def peaks_decode(hm, reg=None, tracking=None, ws=None):
                ys=torch.empty(B, K, dtype=torch.int64, device=dev),
                regs=torch.zeros(B, K, 2, dtype=torch.float32, device=dev),
                trks=torch.zeros(B, K, 2, dtype=torch.float32, device=dev),
-               npeaks=torch.empty(B, K, dtype=torch.int32, device=dev))
-    _lib.call("sgta_peaks_decode", hm.data_ptr(), None if reg is None else _req(reg.contiguous()).data_ptr(),
+               npeaks=torch.empty(B, K, dtype=torch.int32, device=dev),
+               cts=torch.empty(B, K, 2, dtype=torch.int64, device=dev))
+    if reg is not None:
+        out["cts_wreg"] = torch.empty(B, K, 2, dtype=torch.float32, device=dev)
+        out["regs_rel"] = torch.empty(B, K, 2, dtype=torch.float32, device=dev)
+    _lib.call("sgta_peaks_decode_full", hm.data_ptr(), None if reg is None else _req(reg.contiguous()).data_ptr(),
               None if tracking is None else _req(tracking.contiguous()).data_ptr(),
               gauss_taps(dev).data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), out["scores"].data_ptr(),
               out["xs"].data_ptr(), out["ys"].data_ptr(), out["regs"].data_ptr(), out["trks"].data_ptr(),
-              out["npeaks"].data_ptr(), B, K, H, W, _stream())
+              out["npeaks"].data_ptr(), out["cts"].data_ptr(),
+              out["cts_wreg"].data_ptr() if reg is not None else None,
+              out["regs_rel"].data_ptr() if reg is not None else None, B, K, H, W, int(three_pass), _stream())
     return out
 
 

@@ -379,6 +379,36 @@ def test_gaussian_filter_bit_exact_vs_scipy(ops):
                 assert np.array_equal(got[b, k], gaussian_filter(m[b, k].numpy(), sigma=3))
 
 
+def test_fused_decode_equals_three_pass(ops):
+    """One-kernel Gaussian + local maxima + per-tile candidates (24-row tiles merged by a second kernel) against the
+    three-kernel form: identical filtered maps and identical dictionaries, on map heights that are not tile multiples,
+    peaks on tile seams, several peaks per map, empty maps and plateaus."""
+    rng = np.random.RandomState(5)
+    for (B, K, H, W) in ((2, 7, 120, 160), (1, 3, 49, 37), (2, 2, 24, 40), (1, 2, 25, 13), (1, 1, 15, 9)):
+        hm = np.zeros((B, K, H, W), np.float32)
+        for b in range(B):
+            for k in range(K):
+                for _ in range(rng.randint(0, 4)):
+                    cy, cx = rng.randint(0, H), rng.randint(0, W)
+                    if rng.rand() < 0.4:
+                        cy = min(H - 1, 24 * rng.randint(0, (H + 23) // 24) + rng.randint(-1, 1) % H)   # tile seams
+                    yy, xx = np.mgrid[0:H, 0:W]
+                    hm[b, k] = np.maximum(hm[b, k], rng.uniform(0.3, 1.0) *
+                                          np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * rng.uniform(1.0, 3.0) ** 2)))
+        hm[0, 0, : min(H, 6), : min(W, 6)] = 0.5                      # a plateau
+        reg = rng.rand(B, 2, H, W).astype(np.float32)
+        trk = rng.randn(B, 2, H, W).astype(np.float32)
+        h, r, t_ = (torch.from_numpy(a).to(DEV) for a in (hm, reg, trk))
+        ws_a = (torch.empty_like(h), torch.empty_like(h))
+        ws_b = (torch.empty_like(h), torch.empty_like(h))
+        a = ops.peaks_decode(h, r, t_, ws=ws_a)
+        b_ = ops.peaks_decode(h, r, t_, ws=ws_b, three_pass=True)
+        assert torch.equal(ws_a[1], ws_b[1])
+        for k in b_:
+            assert torch.equal(a[k], b_[k]), k
+        assert int(a["npeaks"].sum()) > 0
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["128", "128_first", "96x160", "480", "480x640"])
 def test_fullnet_matches_reference(model, tag):
