@@ -33,6 +33,7 @@ struct WinoArgs {
   int nchunks, blk_r, blk_c, n_ct, n_pt, vec;      // vec: 4 / 2 / 1 pixels per store
   int ksplit;                      // > 1: item = (block, channel group, K slice); raw partial sums go to ``part``
   float* part;                     // [ksplit][B][Cout][H][W]
+  int ni, tri;                     // ni > 1: a block stacks ni images of tri tile rows each (small maps), else tri = TR
 };
 
 // padded, de-interleaved window row length: 2*WWP == 32/(32/TC) (mod 32) puts the tile rows of a 16-lane group on
@@ -116,20 +117,40 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino_kern
     const int ks = item % a.ksplit, rest = item / a.ksplit;
     const int pt = rest / a.n_ct, ct = rest - pt * a.n_ct;
     kbase = ks * nch;
-    const int b = pt / blks, rem = pt - b * blks;
-    const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
-    const int oy0 = 2 * br * TR, ox0 = 2 * bc * TC;
+    int b, ox0;
+    if (a.ni > 1) {
+      // STACKED small maps (H <= 2*tri - 1, blk_r == 1): image si of the block owns window rows si*2*tri .. (si+1)*2*tri;
+      // its last row (gy = 2*tri - 1 >= H) is the zero padding that image si + 1 needs above its first row, so the
+      // window keeps its 2*TR + 2 rows and a tile's LDS base stays (2*trow)*WWP -- only the DMA sources change
+      const int bq = pt / a.blk_c, bc = pt - bq * a.blk_c;
+      b = bq * a.ni;
+      ox0 = 2 * bc * TC;
+      const int S = 2 * a.tri;
 #pragma unroll
-    for (int q = 0; q < ROUNDS; ++q) {
-      const int gy = oy0 + slot_r[q], gx = ox0 + slot_c[q];
-      const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      poff[q] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+      for (int q = 0; q < ROUNDS; ++q) {
+        const int r = slot_r[q] + 1;                  // window row (negative: slot outside the window)
+        const int si = r / S, gy = r - si * S - 1, gx = ox0 + slot_c[q];
+        const bool ok = r >= 0 && si < a.ni && b + si < a.B && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        poff[q] = ok ? (unsigned)(si * a.x_bs + gy * W + gx) * 4u : 0x80000000u;
+      }
+    } else {
+      b = pt / blks;
+      const int rem = pt - b * blks;
+      const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
+      const int oy0 = 2 * br * TR;
+      ox0 = 2 * bc * TC;
+#pragma unroll
+      for (int q = 0; q < ROUNDS; ++q) {
+        const int gy = oy0 + slot_r[q], gx = ox0 + slot_c[q];
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        poff[q] = ok ? (unsigned)(gy * W + gx) * 4u : 0x80000000u;
+      }
     }
 #pragma unroll
     for (int q = 0; q < U_PER; ++q) uoff[q] = (unsigned)(uslot[q] + ct * BM * LDU * 4);
 #if defined(__HIP_DEVICE_COMPILE__)
-    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.x_bs), (short)0, a.Cin * HW * 4,
-                                            0x00020000);
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (long)b * a.x_bs), (short)0,
+                                            (int)(((a.ni - 1) * a.x_bs + (long)a.Cin * HW) * 4), 0x00020000);
 #endif
   };
   // one chunk = three DMA batches (window channels 0-3, window channels 4-7, U) so that the issue can be
@@ -269,9 +290,20 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino_kern
     // ---- output transform in registers: lane = tile t, output channels i*16 + 4g + r -----------------------
     {
       const int pt = item / (a.ksplit * a.n_ct);
-      const int b = pt / blks, rem = pt - b * blks;
-      const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
-      const int oy = 2 * br * TR + 2 * trow, ox = 2 * bc * TC + 2 * tcol;
+      int b, oy, ox;
+      if (a.ni > 1) {                                // stacked small maps: the tile row selects the image
+        const int bq = pt / a.blk_c, bc = pt - bq * a.blk_c, si = trow / a.tri;
+        b = bq * a.ni + si;
+        oy = b < a.B ? 2 * (trow - si * a.tri) : H;  // images beyond the batch: nothing to store
+        ox = 2 * bc * TC + 2 * tcol;
+        if (b >= a.B) b = a.B - 1;
+      } else {
+        b = pt / blks;
+        const int rem = pt - b * blks;
+        const int br = rem / a.blk_c, bc = rem - br * a.blk_c;
+        oy = 2 * br * TR + 2 * trow;
+        ox = 2 * bc * TC + 2 * tcol;
+      }
       // split-K: raw partial sums (no bias; launched as ACT = RES = 0) go to slice ks of the workspace
       float* const ybase = a.ksplit > 1 ? a.part + (long)ks * a.B * a.Cout * HW : a.y;
       const long ybs = a.ksplit > 1 ? (long)a.Cout * HW : a.y_bs;
@@ -391,6 +423,16 @@ static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) 
     a.blk_r = cdiv(cdiv(a.H, 2), TR);
     a.blk_c = cdiv(cdiv(a.W, 2), TC);
     a.n_pt = a.B * a.blk_r * a.blk_c;
+    // small maps: ni images share a block, tri = TR / ni tile rows each (needs H <= 2*tri - 1, see the kernel's setup)
+    a.ni = 1;
+    a.tri = TR;
+    for (int n = 4; n >= 2; n >>= 1)
+      if (TR % n == 0 && a.H <= 2 * (TR / n) - 1 && a.B >= 2 && ((n - 1) * a.x_bs + (long)a.Cin * a.H * a.W) * 4 <= 0x7fffffffL) {
+        a.ni = n;
+        a.tri = TR / n;
+        a.n_pt = cdiv(a.B, n) * a.blk_c;
+        break;
+      }
     // persistent: as many work-groups as the device holds at once (2 per CU), never more than items
     static int resident_by_tile[4] = {0, 0, 0, 0};          // per <ACT, RES> instance and tile shape
     int& resident = resident_by_tile[tile];

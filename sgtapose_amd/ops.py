@@ -189,12 +189,18 @@ class PackedConv:
         return best
 
     def wino_tile(self, H, W):
-        """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape."""
+        """Tile code for sgta_conv3x3_wino_f32: best-filling 64-tile block shape.  Maps of at most 2*tr/n - 1 rows
+        are stacked n images to a block by the kernel (same rule as launch_wino in conv3x3_wino.hip)."""
         ty, tx = -(-H // 2), -(-W // 2)
         best = None
         for code, tc in ((0, 32), (1, 16), (2, 8), (3, 4)):
             tr = 64 // tc
-            util = (ty * tx) / float((-(-ty // tr) * tr) * (-(-tx // tc) * tc))
+            rows = -(-ty // tr) * tr
+            for n in (4, 2):
+                if tr % n == 0 and H <= 2 * (tr // n) - 1:
+                    rows = tr // n
+                    break
+            util = (ty * tx) / float(rows * (-(-tx // tc) * tc))
             if best is None or util > best[1] + 1e-9:
                 best = (code, util)
         return best[0]
@@ -295,7 +301,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
                       res_mode if res is not None else 0, code, _stream(), meta=meta)
             return out
     if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
-        code = pc.wino_tile(x.H, x.W)
+        code = pc.wino_tile(x.H, x.W) if WINO_TILE_OVERRIDE is None else WINO_TILE_OVERRIDE
         meta = None
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, False)
@@ -340,6 +346,7 @@ def _splitk_ws(dev, nfloats):
 
 
 LINEAR_SPLITK_MAX_ROWS = 1024   # token GEMMs with at most this many rows may split K (0 disables)
+WINO_TILE_OVERRIDE = None      # tests / tools: force the F(2x2,3x3) block shape (tile code 0..3)
 USE_WINO4 = True               # F(4x4,3x3) where the map fills its 64-tile blocks (else F(2x2,3x3))
 WINO4_MIN_FILL = 0.7           # minimum useful fraction of the 4x4-tile blocks
 USE_WINOGRAD = True            # 3x3 s1 convs with Cin % 8 == 0 go through Winograd F(2x2,3x3) (fp32)

@@ -88,6 +88,37 @@ def test_conv3x3_implementations_agree(ops, cin, cout, H, W):
         ops.USE_WINOGRAD, ops.USE_PATCH_KERNEL, ops.USE_WINO4, ops.WINO4_MIN_FILL = flags
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(3, 16, 32, 15, 20), (5, 8, 40, 7, 12), (2, 24, 27, 3, 5), (1, 8, 32, 15, 20),
+                                            (64, 32, 32, 15, 20), (7, 16, 64, 5, 9)])
+def test_winograd_stacks_small_maps(ops, B, cin, cout, H, W):
+    """F(2x2,3x3) puts 2 or 4 small images (H <= 2*rows - 1) into one 64-tile block; the zero row between them is shared.
+    Odd batch sizes leave empty image slots in the last block; residual, split-K (27 channels, no activation) and
+    every tile code must agree with torch."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV))
+    old = ops.USE_WINO4
+    ops.USE_WINO4 = False
+    try:
+        for code in (None, 0, 1, 2, 3):              # automatic, then every block shape
+            ops.WINO_TILE_OVERRIDE = code
+            out = torch.full(ref.shape, 7.0, device=DEV)
+            ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU, res=res.to(DEV), res_mode=1)
+            err = float((out.cpu() - F.relu(ref + res)).abs().max())
+            assert err < 1e-4, (code, err)
+        ops.WINO_TILE_OVERRIDE = None
+        out = torch.full(ref.shape, 7.0, device=DEV)
+        ops.conv2d(x.to(DEV), pc, out, ops.ACT_NONE)
+        assert float((out.cpu() - ref).abs().max()) < 1e-4
+    finally:
+        ops.USE_WINO4 = old
+        ops.WINO_TILE_OVERRIDE = None
+
+
 @pytest.mark.parametrize("cin,H,W", [(512, 15, 20), (256, 30, 40), (64, 9, 7)])
 def test_winograd_split_k_offset_conv(ops, cin, H, W):
     """The 27-channel DCN offset convs of the small levels are split over slices of the input channels (few work
