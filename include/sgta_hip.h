@@ -184,6 +184,16 @@ int sgta_linear_ws_f32(const float* x, int ldx, const float* w, const float* bia
                        int ldr, const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M,
                        int N, int K, int relu, float* ws, long ws_floats, sgta_stream_t stream);
 
+/* y[M,C] = LayerNorm( x + W2 . relu(W1 . x + b1) + b2 ): the position-wise feed-forward block of
+ * TransformerEncoderLayer (linear1 / ReLU / linear2 / residual / norm3, dla.py:721-732, :737-738; eps 1e-5) in ONE
+ * kernel -- the [M,F] hidden activations stay in registers (the accumulator of the first MFMA product is the B operand
+ * of the second).  x / y row-major with leading dimensions ldx / ldy (multiples of 4, y may not alias x);
+ * w1 [F,C], b1 [F], w2 [C,F], b2 [C], ln_gamma / ln_beta [C]; C in {16,32,64}, F % 16 == 0; all pointers 16-byte
+ * aligned. */
+int sgta_ffn_ln_f32(const float* x, int ldx, const float* w1, const float* b1, const float* w2, const float* b2,
+                    const float* ln_gamma, const float* ln_beta, float* y, int ldy, int M, int C, int F,
+                    sgta_stream_t stream);
+
 /* out[b,i,h*d:(h+1)*d] = softmax_j(q_i.k_j/sqrt(d) + pos_embed[h,i,j]) . v_j  per head
  * (MHCA_ein.forward, dla.py:874-885); q/k/v/out row-major [B*n, ld*]; pos_embed [n_heads,n,n] or NULL;
  * head_dim in {4,8,16}. */

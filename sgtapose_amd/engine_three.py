@@ -44,9 +44,10 @@ class EngineThree(Engine):
             ops.linear(cur, T["wq"], None, q)
             ops.mhca(q, kv[:, :hid], kv[:, hid:], T["pos"], att, B, n, N_HEADS, hid // N_HEADS)
             ops.linear(att, T["fc_w"], T["fc_b"], y1, res=cur, ln=T["ln1"])
-            ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
             dst = out if it == 2 else nxt[it]
-            ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
+            if ops.ffn_ln(y1, T["w1"], T["b1"], T["w2"], T["b2"], T["ln3"], dst) is None:
+                ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
+                ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
             cur = dst
 
     def temporal_three(self, lv, idx_pp, idx_p, B):

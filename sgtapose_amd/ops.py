@@ -513,6 +513,24 @@ def linear(x, w, bias, out, relu=False, res=None, ln=None, K=None):
     return out
 
 
+USE_FUSED_FFN = True            # encoder feed-forward block in one kernel (False: two linear launches, tests)
+
+
+def ffn_ln(x, w1, b1, w2, b2, ln, out):
+    """out = LayerNorm(x + relu(x @ w1.T + b1) @ w2.T + b2): fused feed-forward block (sgta_ffn_ln_f32) when the
+    shape / alignment contract holds, else None (the caller falls back to two ``linear`` calls)."""
+    M, C = x.shape
+    F = w1.shape[0]
+    ok = (USE_FUSED_FFN and C in (16, 32, 64) and F % 16 == 0 and x.stride(-1) == 1 and out.stride(-1) == 1
+          and x.stride(0) % 4 == 0 and out.stride(0) % 4 == 0 and w1.is_contiguous() and w2.is_contiguous()
+          and all(t.data_ptr() % 16 == 0 for t in (x, out, w1, b1, w2, b2, ln[0], ln[1])))
+    if not ok:
+        return None
+    _lib.call("sgta_ffn_ln_f32", x.data_ptr(), x.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+              ln[0].data_ptr(), ln[1].data_ptr(), out.data_ptr(), out.stride(0), M, C, F, _stream())
+    return out
+
+
 def mhca(q, k, v, pos, out, B, n, n_heads, head_dim):
     """q/k/v/out: 2-D [B*n, ld] row-major views (column slices allowed)."""
     _lib.call("sgta_mhca_fwd_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),

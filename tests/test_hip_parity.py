@@ -329,6 +329,32 @@ def test_linear_with_relu_residual_layernorm(ops):
             assert torch.allclose(out.cpu(), F.layer_norm(ref + r, (N,), gm, bt, 1e-5), atol=5e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,C", [(37, 16), (1183, 16), (4100, 16), (343, 32), (8300, 32), (63, 64), (2016, 64), (33000, 16)])
+def test_fused_feed_forward_block(ops, M, C):
+    """LayerNorm(x + W2 relu(W1 x + b1) + b2) in one kernel (hidden activations in registers, dla.py:721-738) against
+    torch and against the two-launch form; strided output view (the last encoder iteration writes into cat_tok)."""
+    g = torch.Generator().manual_seed(M + C)
+    Fh = 1024
+    x = torch.randn(M, C, generator=g)
+    w1 = torch.randn(Fh, C, generator=g) / C ** 0.5
+    b1 = torch.randn(Fh, generator=g) * 0.1
+    w2 = torch.randn(C, Fh, generator=g) / Fh ** 0.5
+    b2 = torch.randn(C, generator=g) * 0.1
+    gm, bt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    ref = F.layer_norm(x + F.linear(F.relu(F.linear(x, w1, b1)), w2, b2), (C,), gm, bt, 1e-5)
+    d = [t_.to(DEV) for t_ in (x, w1, b1, w2, b2, gm, bt)]
+    wide = torch.full((M, 2 * C), 7.0, device=DEV)
+    out = wide[:, :C]
+    assert ops.ffn_ln(d[0], d[1], d[2], d[3], d[4], (d[5], d[6]), out) is not None
+    assert torch.allclose(out.cpu(), ref, atol=5e-5, rtol=1e-5), float((out.cpu() - ref).abs().max())
+    assert float(wide[:, C:].min()) == 7.0                      # nothing written beside the view
+    hdn = torch.empty(M, Fh, device=DEV)
+    two = torch.empty(M, C, device=DEV)
+    ops.linear(d[0], d[1], d[2], hdn, relu=True)
+    ops.linear(hdn, d[3], d[4], two, res=d[0], ln=(d[5], d[6]))
+    assert torch.allclose(out, two, atol=5e-5, rtol=1e-5)
+
+
 def test_linear_split_k_matches_direct_and_is_deterministic(ops):
     """The few-hundred-token products of cat_layer (dla.py:1537-1543) split K over work-groups: same results as the
     un-split kernel within fp32 summation-order noise, bit-identical from run to run, residual / ReLU after the sum."""
