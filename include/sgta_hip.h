@@ -201,6 +201,14 @@ int sgta_mhca_fwd_f32(const float* q, int ldq, const float* k, int ldk, const fl
                       const float* pos_embed, float* out, int ldo, int B, int n, int n_heads,
                       int head_dim, sgta_stream_t stream);
 
+/* Same operator with the bias parameter re-packed ONCE (it is a weight) into 16 x 16 tiles, T = ceil(n / 16):
+ * pos_tiles[((h*T + it)*T + jt)*256 + li*16 + c] = pos_embed[h][it*16 + li][jt*16 + c], -inf for key columns >= n
+ * (the padding mask), any finite value for query rows >= n; 16-byte aligned.  One coalesced 16-byte load per lane and
+ * key tile replaces four strided 4-byte loads. */
+int sgta_mhca_tiled_fwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                            const float* pos_tiles, float* out, int ldo, int B, int n, int n_heads,
+                            int head_dim, sgta_stream_t stream);
+
 /* peaks_from_belief_maps + _peaks_info + the gathers of dream_generic_decode
  * (sgtapose/image_proc.py:1032-1143; sgtapose/lib/model/utils.py:207-284; sgtapose/lib/model/decode.py:184-313)
  * for EVERY sample of the batch.  hm [B,K,H,W] post-sigmoid; reg / tracking [B,2,H,W] or NULL;

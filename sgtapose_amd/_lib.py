@@ -38,6 +38,7 @@ SIGNATURES = {
     "sgta_linear_ws_f32": [_p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _l, _p],
     "sgta_ffn_ln_f32": [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "sgta_mhca_fwd_f32": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_mhca_tiled_fwd_f32": [_p, _i, _p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_peaks_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "sgta_peaks_decode_full": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_render_priors": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

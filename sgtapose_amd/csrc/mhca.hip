@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
                                                    const float* __restrict__ k, int ldk,
                                                    const float* __restrict__ v, int ldv,
                                                    const float* __restrict__ pos,
+                                                   const float* __restrict__ post,
                                                    float* __restrict__ out, int ldo, int n, int npad,
                                                    float inv_scale) {
   extern __shared__ float smem[];
@@ -58,11 +59,20 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
 #pragma unroll
     for (int c = 0; c < D / 4; ++c) qf[c] = q[((long)b * n + ic) * ldq + h * D + c * 4 + g];
     const float* prow = posh ? posh + (long)ic * n : nullptr;
+    // tiled bias (sgta_mhca_tiled_fwd_f32): [head][query tile][key tile][16 queries][16 keys], -inf baked in beyond n:
+    // one coalesced 16-byte load per lane and key tile instead of four strided 4-byte ones
+    const float* ptile = post ? post + (((long)h * ntile + it) * ntile) * 256 + li * 16 + 4 * g : nullptr;
 
     float m = -INFINITY, lsum = 0.0f;
     f32x4 o = {0, 0, 0, 0};
     float bias[4], bias_nx[4];
     auto load_bias = [&](int jt, float* dst) {
+      if (ptile) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(ptile + (long)jt * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = t4[r];
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int j = jt * 16 + 4 * g + r;
@@ -110,11 +120,12 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
   }
 }
 
-extern "C" int sgta_mhca_fwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v,
-                                 int ldv, const float* pos_embed, float* out, int ldo, int B, int n,
-                                 int n_heads, int head_dim, hipStream_t st) {
+static int mhca_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                       const float* pos_embed, const float* pos_tiles, float* out, int ldo, int B, int n, int n_heads,
+                       int head_dim, hipStream_t st) {
   if (!q || !k || !v || !out || B <= 0 || n <= 0 || n_heads <= 0) return SGTA_EBADARG;
   if ((ldq | ldk | ldv | ldo) & 3) return SGTA_EBADARG;
+  if (pos_tiles && ((uintptr_t)pos_tiles & 15)) return SGTA_EBADARG;
   const int npad = (n + 15) / 16 * 16;
   const int ntile = npad / 16;
   int qsplit = (ntile + 3) / 4;                    // work-groups along the query axis
@@ -123,11 +134,27 @@ extern "C" int sgta_mhca_fwd_f32(const float* q, int ldq, const float* k, int ld
   const float inv = 1.0f / sqrtf((float)head_dim);
   size_t lds = (size_t)2 * head_dim * (npad + 4) * sizeof(float);
   switch (head_dim) {
-    case 4: hipLaunchKernelGGL(mhca_kernel<4>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, out, ldo, n, npad, inv); break;
-    case 8: hipLaunchKernelGGL(mhca_kernel<8>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, out, ldo, n, npad, inv); break;
-    case 16: hipLaunchKernelGGL(mhca_kernel<16>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, out, ldo, n, npad, inv); break;
+    case 4: hipLaunchKernelGGL(mhca_kernel<4>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
+    case 8: hipLaunchKernelGGL(mhca_kernel<8>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
+    case 16: hipLaunchKernelGGL(mhca_kernel<16>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
     default: return SGTA_EBADARG;
   }
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
+}
+
+extern "C" int sgta_mhca_fwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v,
+                                 int ldv, const float* pos_embed, float* out, int ldo, int B, int n,
+                                 int n_heads, int head_dim, hipStream_t st) {
+  return mhca_launch(q, ldq, k, ldk, v, ldv, pos_embed, nullptr, out, ldo, B, n, n_heads, head_dim, st);
+}
+
+// Same operator with the bias re-packed once by the caller into 16 x 16 tiles:
+//   pos_tiles[((h * T + it) * T + jt) * 256 + li * 16 + c] = pos_embed[h][it*16 + li][jt*16 + c]   (T = ceil(n / 16)),
+//   -inf where jt*16 + c >= n (the key padding mask), anything finite where it*16 + li >= n.
+extern "C" int sgta_mhca_tiled_fwd_f32(const float* q, int ldq, const float* k, int ldk, const float* v,
+                                       int ldv, const float* pos_tiles, float* out, int ldo, int B, int n,
+                                       int n_heads, int head_dim, hipStream_t st) {
+  if (!pos_tiles) return SGTA_EBADARG;
+  return mhca_launch(q, ldq, k, ldk, v, ldv, nullptr, pos_tiles, out, ldo, B, n, n_heads, head_dim, st);
 }

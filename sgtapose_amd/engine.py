@@ -113,7 +113,8 @@ class Engine:
         ca = lay.cross_attn
         return dict(
             wq=f(ca.w_q.weight), wkv=torch.cat([f(ca.w_k.weight), f(ca.w_v.weight)], 0).contiguous(),
-            fc_w=f(ca.fc.weight), fc_b=f(ca.fc.bias), pos=f(ca.pos_embed) if self.use_pos else None,
+            fc_w=f(ca.fc.weight), fc_b=f(ca.fc.bias),
+            pos=ops.PosTiles(f(ca.pos_embed)) if self.use_pos else None,     # re-packed once: it is a weight
             ln1=(f(lay.norm1.weight), f(lay.norm1.bias)), ln3=(f(lay.norm3.weight), f(lay.norm3.bias)),
             w1=f(lay.linear1.weight), b1=f(lay.linear1.bias), w2=f(lay.linear2.weight), b2=f(lay.linear2.bias),
             n=ca.n, C=ca.inp_dim, hid=ca.hid_dim)

@@ -532,11 +532,32 @@ def ffn_ln(x, w1, b1, w2, b2, ln, out):
 
 
 def mhca(q, k, v, pos, out, B, n, n_heads, head_dim):
-    """q/k/v/out: 2-D [B*n, ld] row-major views (column slices allowed)."""
+    """q/k/v/out: 2-D [B*n, ld] row-major views (column slices allowed).  ``pos``: [n_heads, n, n] bias, a ``PosTiles``
+    (the same bias re-packed by ``pack_pos_tiles``), or None."""
+    if isinstance(pos, PosTiles):
+        assert pos.n == n and pos.tiles.shape[0] == n_heads
+        _lib.call("sgta_mhca_tiled_fwd_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                  v.stride(0), pos.tiles.data_ptr(), out.data_ptr(), out.stride(0), B, n, n_heads, head_dim, _stream())
+        return out
     _lib.call("sgta_mhca_fwd_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
               v.stride(0), None if pos is None else pos.data_ptr(), out.data_ptr(), out.stride(0), B, n,
               n_heads, head_dim, _stream())
     return out
+
+
+class PosTiles:
+    """The structure-prior bias [heads, n, n] (MHCA_ein.pos_embed, dla.py:866-868) in the 16 x 16-tile layout of
+    sgta_mhca_tiled_fwd_f32: tiles[h, it, jt, li, c] = pos[h, 16 it + li, 16 jt + c]; key columns beyond n are -inf
+    (the padding mask the kernel would otherwise apply), query rows beyond n are 0."""
+
+    def __init__(self, pos):
+        heads, n, _ = pos.shape
+        T = -(-n // 16)
+        full = torch.zeros(heads, T * 16, T * 16, dtype=torch.float32, device=pos.device)
+        full[:, :, n:] = float("-inf")
+        full[:, :n, :n] = pos
+        self.n = n
+        self.tiles = full.view(heads, T, 16, T, 16).permute(0, 1, 3, 2, 4).contiguous()
 
 
 _GAUSS = {}
