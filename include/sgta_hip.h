@@ -103,7 +103,8 @@ int sgta_conv1x1_skinny_f32(const float* x, long x_bs, const float* w, const flo
 
 /* conv3x3 / stride 2 / pad 1 + folded BN + ReLU (first conv of the down-sampling BasicBlocks, level1;
  * dla.py:44-46, :248-249): 2-D output tiles, de-interleaved input window staged by LDS-DMA.
- * wt : packed [Cin/4][Cout_pad][36] (same layout as sgta_conv3x3s1_f32), Cin % 4 == 0.
+ * wt : packed k-major [Cin/4][36][Cout_pad], k = c_local*9 + tap (the layout of sgta_dcnv2_lds_f32: rows of
+ * consecutive output channels, staged by 16-byte LDS-DMA), Cin % 4 == 0, 16-byte aligned.
  * tile = 10*MT + t: MT in {1,2} = 32 / 64 output channels per work-group, t in {0,1,2} = 8x32 / 16x16 / 32x8 tiles. */
 int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y, long y_bs,
                        int B, int Cin, int H, int W, int Cout, int Cout_pad, int tile, sgta_stream_t stream);

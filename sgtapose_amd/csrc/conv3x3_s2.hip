@@ -1,7 +1,8 @@
 // 3x3 / stride 2 / pad 1 convolution + folded BN + ReLU (the first conv of every down-sampling BasicBlock and
 // level1 of DLA-34; reference dla.py:44-46, :248-249, :302-312) for gfx950, f32 MFMA 32x32x2.
 // 2-D output tile of 256 pixels (TH x TW); the (2TH+1) x (2TW+1) input window of 4 channels at a time is
-// staged by LDS-DMA (double buffered, zero-filled outside the image) with its columns DE-INTERLEAVED
+// staged by buffer LDS-DMA (double buffered; scalar chunk offsets, out-of-image slots carry an out-of-range offset
+// that the hardware bounds check turns into zeros) with its columns DE-INTERLEAVED
 // ([even | odd], padded so that the tile rows of a 32-lane group hit disjoint banks): the stride-2 reads of
 // neighbouring output pixels become unit-stride and conflict-free.  Lane half = channel of a pair, the nine
 // k-steps of a pair are the taps (as in conv3x3_patch.hip).
@@ -9,14 +10,12 @@
 
 struct S2Args {
   const float* x;  long x_bs;
-  const float* wt;                 // [Cin/4][Cout_pad][36], k_local = c_local*9 + tap
+  const float* wt;                 // [Cin/4][36][Cout_pad], k_local = c_local*9 + tap (k-major rows)
   const float* bias;               // [Cout_pad]
   float* y;        long y_bs;
   int B, Cin, H, W, Ho, Wo, Cout, Cout_pad;
   int nchunks, tiles_x, tiles_y, n_ct, n_pt;
 };
-
-__device__ float sgta_s2_zero = 0.0f;
 
 __host__ __device__ constexpr int s2_wwp(int TW) { return TW == 8 ? 20 : (TW == 16 ? 40 : 2 * TW + 2); }
 
@@ -24,11 +23,14 @@ template <int MT, int TW>
 __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   constexpr int NT = 2, BM = MT * 32, TH = 256 / TW, CK = 4;
   constexpr int WH = 2 * TH + 1, WW = 2 * TW + 1, NE = TW + 1, WWP = s2_wwp(TW), WSZ = WH * WWP;
-  constexpr int KC = CK * 9, LDA = KC + 1;
-  constexpr int P_TOT = CK * WSZ, A_TOT = BM * LDA;
-  constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_TOT + 255) / 256;
-  constexpr int STAGE = (P_PER + A_PER) * 256;
-  __shared__ float lds[2 * STAGE + BM];
+  constexpr int KC = CK * 9;
+  // weights: k-major rows As[k][BM] (a lane's A operand = consecutive output channels: conflict-free), staged by
+  // 16-byte LDS-DMA; window: 4-byte slots (de-interleaved columns)
+  constexpr int P_TOT = CK * WSZ, A_SLOTS = KC * BM / 4;
+  constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_SLOTS + 255) / 256;
+  static_assert(A_SLOTS >= 256, "weight tile smaller than one DMA round");
+  constexpr int STAGE = P_PER * 256 + KC * BM;
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + BM];
   float* const sbias = lds + 2 * STAGE;
 
   int pt, ct;
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   const float* xb = a.x + (long)b * a.x_bs;
   if (tid < BM) sbias[tid] = a.bias[ct * BM + tid];
 
-  int poff[P_PER], aoff[A_PER];
+  // per-slot byte offsets are chunk-invariant VGPRs, the chunk advance is the scalar offset of the buffer load
+  unsigned poff[P_PER], aoff[A_PER];
 #pragma unroll
   for (int t = 0; t < P_PER; ++t) {
     const int e = tid + t * 256;
@@ -55,25 +58,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
     const int col = sx < NE ? 2 * sx : 2 * (sx - NE) + 1;
     const int gy = wy0 + r / WWP, gx = wx0 + col;
     const bool ok = e < P_TOT && sx < WW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    poff[t] = ok ? c * HW + gy * W + gx : -1;
+    poff[t] = ok ? (unsigned)(c * HW + gy * W + gx) * 4u : 0x80000000u;
   }
 #pragma unroll
   for (int t = 0; t < A_PER; ++t) {
-    const int e = tid + t * 256;
-    const int row = e / LDA, col = e - row * LDA;
-    aoff[t] = (e < A_TOT && col < KC) ? row * KC + col : -1;
+    // 16-byte slot e = (k, quarter); the last round is shifted back so that every DMA runs with all 256 lanes
+    const int e = tid + (t < A_PER - 1 ? t * 256 : A_SLOTS - 256);
+    const int k = e / (BM / 4), s4 = e - k * (BM / 4);
+    aoff[t] = (unsigned)(k * a.Cout_pad + ct * BM + s4 * 4) * 4u;
   }
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, a.Cin * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wt), (short)0, (a.Cin / CK) * KC * a.Cout_pad * 4, 0x00020000);
+#endif
   auto stage = [&](int kc, int st) {
+#if defined(__HIP_DEVICE_COMPILE__)
     float* dst = lds + st * STAGE + wave * 64;
-    const float* xc = xb + (long)kc * CK * HW;
 #pragma unroll
     for (int t = 0; t < P_PER; ++t)
-      __builtin_amdgcn_global_load_lds(poff[t] >= 0 ? xc + poff[t] : &sgta_s2_zero, dst + t * 256, 4, 0, 0);
-    const float* src = a.wt + ((long)kc * a.Cout_pad + ct * BM) * KC;
-    float* adst = dst + P_PER * 256;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 256), 4, poff[t], kc * CK * HW * 4, 0, 0);
+    float* adst = lds + st * STAGE + P_PER * 256 + wave * 256;
 #pragma unroll
     for (int t = 0; t < A_PER; ++t)
-      __builtin_amdgcn_global_load_lds(aoff[t] >= 0 ? src + aoff[t] : &sgta_s2_zero, adst + t * 256, 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + (t < A_PER - 1 ? t * 1024 : A_SLOTS * 4 - 1024)), 16,
+                                               aoff[t], kc * KC * a.Cout_pad * 4, 0, 0);
+#endif
   };
 
   int tbase[NT], oy[NT], ox[NT];
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
 #pragma unroll
     for (int q = 0; q < CK / 2; ++q) {
       const float* prow = win + (2 * q + lh) * WSZ;
-      const float* arow = As + l31 * LDA + (2 * q + lh) * 9;
+      const float* arow = As + ((2 * q + lh) * 9) * BM + l31;       // row k = channel*9 + tap, column = output channel
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         constexpr int dummy = 0; (void)dummy;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
         const int toff = ky * WWP + (kx & 1) * NE + (kx >> 1);
         float av[MT], bv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[i] = arow[i * 32 * LDA + tap];
+        for (int i = 0; i < MT; ++i) av[i] = arow[tap * BM + i * 32];
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[j] = prow[tbase[j] + toff];
 #pragma unroll

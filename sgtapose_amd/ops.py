@@ -147,6 +147,12 @@ class PackedConv:
             u4 = torch.zeros(ci // 4, 4, self.Cout_pad, 36, dtype=torch.float32, device=w.device)
             u4[:, :, :co] = U4.reshape(co, ci // 4, 4, 36).permute(1, 2, 0, 3)
             self.u_wino4 = u4.contiguous()
+        # 3x3 / stride 2: k-major rows [Cin/4][36][Cout_pad] (k_local = c_local*9 + tap) for sgta_conv3x3s2_f32
+        self.wt_s2 = None
+        if kh == 3 and stride == 2 and self.pad == 1 and ci % 4 == 0 and not tap_major:
+            ws = torch.zeros(ci // 4, 36, self.Cout_pad, dtype=torch.float32, device=w.device)
+            ws[:, :, :co] = w.reshape(co, ci // 4, 36).permute(1, 2, 0)
+            self.wt_s2 = ws.contiguous()
         # DCN main GEMM: layout of the LDS-window kernel, [Cin/4][36][Cout_pad] (k_local = c_local*9 + tap)
         self.wt_dcn8 = None
         if tap_major and kh == 3 and ci % 4 == 0 and self.Cout_pad % 64 == 0:
@@ -273,7 +279,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
                   out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, pc.Kpad, act,
                   res_mode if res is not None else 0, _stream(), meta=meta)
         return out
-    if (USE_S2_KERNEL and pc.ks == 3 and pc.stride == 2 and pc.wt_patch is not None and tile == 0
+    if (USE_S2_KERNEL and pc.ks == 3 and pc.stride == 2 and pc.wt_s2 is not None and tile == 0
             and act == ACT_RELU and res is None):
         code = pc.s2_tile(x.H, x.W)
     else:
@@ -283,7 +289,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, False)
             meta["kernel"] = "conv3x3_s2_kernel<%d,%d>" % (code // 10, (32, 16, 8)[code % 10])
-        _lib.call("sgta_conv3x3s2_f32", x.ptr, x.bs, pc.wt_patch.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
+        _lib.call("sgta_conv3x3s2_f32", x.ptr, x.bs, pc.wt_s2.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
                   x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, code, _stream(), meta=meta)
         return out
     if (USE_WINOGRAD and USE_WINO4 and pc.u_wino4 is not None and tile == 0 and x.W % 4 == 0 and x.bs % 4 == 0
