@@ -24,7 +24,10 @@ __device__ __forceinline__ void c1_glds16(const float* g, float* l) {
 #endif
 }
 
-template <int MT, int ACT, int RES>
+// BUF: buffer-addressed LDS-DMA (per-slot byte offsets are chunk-invariant registers, the chunk advance is the scalar
+// offset, pixel quads beyond M carry an out-of-range offset that the bounds check turns into zeros); needs Cin % 16 == 0
+// and the whole activation tensor inside one 31-bit descriptor -- else the per-lane-address form
+template <int MT, int ACT, int RES, bool BUF>
 __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
   constexpr int NT = 2, BM = MT * 32, BN = 256, CK = 16, LDA = 20, NSTG = 2;
   constexpr int B_SLOTS = CK * BN / 4, A_SLOTS = BM * LDA / 4;          // float4 slots per stage
@@ -57,8 +60,39 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
       xoff[t] = -1;
     }
   }
+  unsigned boff[B_PER], aoffb[A_PER];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t xrs, wrs;
+  if (BUF) {
+#pragma unroll
+    for (int t = 0; t < B_PER; ++t)
+      boff[t] = xoff[t] >= 0 ? (unsigned)((xoff[t] + (long)xch[t] * HW) * 4) : 0x80000000u;
+#pragma unroll
+    for (int t = 0; t < A_PER; ++t) {
+      const int e = tid + t * 256;                     // slots beyond the tile: out of range -> zeros into the stage's padding
+      aoffb[t] = e < A_SLOTS ? (unsigned)(ct * BM * LDA + e * 4) * 4u : 0x80000000u;
+    }
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), (short)0,
+                                            (int)((((long)a.B - 1) * a.x_bs + (long)a.Cin * HW) * 4), 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wt), (short)0, a.nchunks * a.Cout_pad * LDA * 4,
+                                            0x00020000);
+  }
+#endif
   auto stage = [&](int kc, int st) {
     float* dst = lds + st * STAGE + wave * 256;
+    float* adst = lds + st * STAGE + B_SLOTS * 4 + wave * 256;
+    if (BUF) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int t = 0; t < B_PER; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 1024), 16, boff[t], kc * CK * HW * 4, 0, 0);
+#pragma unroll
+      for (int t = 0; t < A_PER; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * 1024), 16, aoffb[t], kc * a.Cout_pad * LDA * 4, 0, 0);
+#endif
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < B_PER; ++t) {
       const int c = kc * CK + xch[t];
@@ -66,7 +100,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args a) {
       c1_glds16(ok ? a.x + xoff[t] + (long)c * HW : sgta_c1_zero, dst + t * 1024);
     }
     const float* src = a.wt + ((long)kc * a.Cout_pad + ct * BM) * LDA;
-    float* adst = lds + st * STAGE + B_SLOTS * 4 + wave * 256;
 #pragma unroll
     for (int t = 0; t < A_PER; ++t)
       if (A_SLOTS % 256 == 0 || tid + t * 256 < A_SLOTS) c1_glds16(src + (tid + t * 256) * 4, adst + t * 1024);
@@ -152,8 +185,11 @@ static int launch_c1(C1Args& a, hipStream_t st) {
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   };
-  if (a.Cout_pad % 64 == 0) return go(conv1x1_kernel<2, ACT, RES>, 64);
-  return go(conv1x1_kernel<1, ACT, RES>, 32);
+  // buffer-addressed staging: whole channel chunks, every offset (incl. one chunk beyond: the scalar part) in 31 bits
+  const bool buf = a.Cin % 16 == 0 && (((long)a.B - 1) * a.x_bs + (long)a.Cin * a.HW) * 4 <= 0x7fffffffL &&
+                   (long)a.nchunks * a.Cout_pad * 20 * 4 <= 0x7fffffffL;
+  if (a.Cout_pad % 64 == 0) return buf ? go(conv1x1_kernel<2, ACT, RES, true>, 64) : go(conv1x1_kernel<2, ACT, RES, false>, 64);
+  return buf ? go(conv1x1_kernel<1, ACT, RES, true>, 32) : go(conv1x1_kernel<1, ACT, RES, false>, 32);
 }
 
 extern "C" int sgta_conv1x1_f32(const float* x, long x_bs, const float* wt, const float* bias,
