@@ -15,6 +15,7 @@ struct S2Args {
   float* y;        long y_bs;
   int B, Cin, H, W, Ho, Wo, Cout, Cout_pad;
   int nchunks, tiles_x, tiles_y, n_ct, n_pt;
+  int ni, thi;                     // ni > 1: a tile stacks ni images of thi output rows each (small maps)
 };
 
 __host__ __device__ constexpr int s2_wwp(int TW) { return TW == 8 ? 20 : (TW == 16 ? 40 : 2 * TW + 2); }
@@ -41,9 +42,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   const int l31 = lane & 31, lh = lane >> 5;
   const int H = a.H, W = a.W, HW = H * W, HWo = a.Ho * a.Wo;
   const int tiles = a.tiles_x * a.tiles_y;
-  const int b = pt / tiles;
-  const int tr = pt - b * tiles;
-  const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;    // output tile origin
+  // STACKED small maps (ni > 1, tiles_y == 1, H <= 2*thi - 1): image si of the tile owns window rows si*2*thi ..
+  // (si+1)*2*thi; its last row (gy = 2*thi - 1 >= H, zero) doubles as the zero row above image si + 1, so the window
+  // keeps its 2*TH + 1 rows and a pixel's LDS base stays (2*ty)*WWP + tx
+  const bool stacked = a.ni > 1;
+  const int b = stacked ? (pt / a.tiles_x) * a.ni : pt / tiles;
+  const int tr = stacked ? pt % a.tiles_x : pt - b * tiles;
+  const int ty0 = stacked ? 0 : (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;    // output tile origin
   const int wy0 = 2 * ty0 - 1, wx0 = 2 * tx0 - 1;                        // input window origin
   const float* xb = a.x + (long)b * a.x_bs;
   if (tid < BM) sbias[tid] = a.bias[ct * BM + tid];
@@ -56,9 +61,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
     const int c = e / WSZ, r = e - c * WSZ;
     const int sx = r % WWP;
     const int col = sx < NE ? 2 * sx : 2 * (sx - NE) + 1;
-    const int gy = wy0 + r / WWP, gx = wx0 + col;
-    const bool ok = e < P_TOT && sx < WW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-    poff[t] = ok ? (unsigned)(c * HW + gy * W + gx) * 4u : 0x80000000u;
+    const int wr = r / WWP, gx = wx0 + col;
+    int gy = wy0 + wr;
+    long img = 0;
+    bool ok = e < P_TOT && sx < WW && (unsigned)gx < (unsigned)W;
+    if (stacked) {
+      const int si = wr / (2 * a.thi);
+      gy = wr - si * 2 * a.thi - 1;
+      img = (long)si * a.x_bs;
+      ok = ok && si < a.ni && b + si < a.B;
+    }
+    ok = ok && (unsigned)gy < (unsigned)H;
+    poff[t] = ok ? (unsigned)((img + c * HW + gy * W + gx) * 4) : 0x80000000u;
   }
 #pragma unroll
   for (int t = 0; t < A_PER; ++t) {
@@ -70,7 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
   const __amdgpu_buffer_rsrc_t xrs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, a.Cin * HW * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0,
+                                        (int)(((a.ni - 1) * a.x_bs + (long)a.Cin * HW) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.wt), (short)0, (a.Cin / CK) * KC * a.Cout_pad * 4, 0x00020000);
 #endif
@@ -88,12 +103,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
 #endif
   };
 
-  int tbase[NT], oy[NT], ox[NT];
+  int tbase[NT], oy[NT], ox[NT], ob[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int pl = (wave * NT + j) * 32 + l31;
     const int ty = pl / TW, tx = pl % TW;
     oy[j] = ty0 + ty; ox[j] = tx0 + tx;
+    ob[j] = b;
+    if (stacked) {                                   // the tile row selects the image
+      const int si = ty / a.thi;
+      ob[j] = b + si;
+      oy[j] = ob[j] < a.B ? ty - si * a.thi : a.Ho;  // image slots beyond the batch store nothing
+      if (ob[j] >= a.B) ob[j] = a.B - 1;
+    }
     tbase[j] = (2 * ty) * WWP + tx;
   }
 
@@ -142,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (oy[j] >= a.Ho || ox[j] >= a.Wo) continue;
-    float* yb = a.y + (long)b * a.y_bs + oy[j] * a.Wo + ox[j];
+    float* yb = a.y + (long)ob[j] * a.y_bs + oy[j] * a.Wo + ox[j];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -170,6 +192,16 @@ extern "C" int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, co
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
     a.n_pt = a.B * a.tiles_x * a.tiles_y;
+    // small maps: ni images share a tile, thi = TH / ni output rows each (needs H <= 2*thi - 1, see the kernel)
+    a.ni = 1;
+    a.thi = TH;
+    for (int n = 4; n >= 2; n >>= 1)
+      if (TH % n == 0 && a.H <= 2 * (TH / n) - 1 && a.B >= 2 && ((n - 1) * a.x_bs + (long)a.Cin * a.H * a.W) * 4 <= 0x7fffffffL) {
+        a.ni = n;
+        a.thi = TH / n;
+        a.n_pt = cdiv(a.B, n) * a.tiles_x;
+        break;
+      }
     int grid = cdiv(a.n_pt, 8) * 8 * a.n_ct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
     SGTA_LAUNCH_CHECK();

@@ -172,16 +172,22 @@ class PackedConv:
         return best
 
     def s2_tile(self, H, W):
-        """Tile code for sgta_conv3x3s2_f32: best-filling 256-pixel output tile."""
+        """Tile code for sgta_conv3x3s2_f32: best-filling 256-pixel output tile.  Inputs of at most 2*th/n - 1 rows are
+        stacked n images to a tile by the kernel (same rule as its launcher)."""
         mt = 2 if self.Cout_pad % 64 == 0 else 1
         ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         best = None
         for code, tw in ((0, 32), (1, 16), (2, 8)):
             th = 256 // tw
-            util = (ho * wo) / float((-(-wo // tw) * tw) * (-(-ho // th) * th))
+            rows = -(-ho // th) * th
+            for n in (4, 2):
+                if th % n == 0 and H <= 2 * (th // n) - 1:
+                    rows = th // n
+                    break
+            util = (ho * wo) / float((-(-wo // tw) * tw) * rows)
             if best is None or util > best[1] + 1e-9:
                 best = (mt * 10 + code, util)
-        return best[0] if best[1] >= 0.7 else 0          # poorly filled tiles: generic implicit GEMM wins
+        return best[0] if best[1] >= S2_MIN_FILL else 0  # poorly filled tiles: generic implicit GEMM wins
 
     def wino4_tile(self, H, W):
         """(tile code, utilisation) of the best-filling 64-tile block shape for sgta_conv3x3_wino4_f32 (4x4 tiles)."""
@@ -352,6 +358,7 @@ def _splitk_ws(dev, nfloats):
 
 
 LINEAR_SPLITK_MAX_ROWS = 1024   # token GEMMs with at most this many rows may split K (0 disables)
+S2_MIN_FILL = 0.7              # minimum useful fraction of the stride-2 kernel's 256-pixel tiles
 WINO_TILE_OVERRIDE = None      # tests / tools: force the F(2x2,3x3) block shape (tile code 0..3)
 USE_WINO4 = True               # F(4x4,3x3) where the map fills its 64-tile blocks (else F(2x2,3x3))
 WINO4_MIN_FILL = 0.7           # minimum useful fraction of the 4x4-tile blocks

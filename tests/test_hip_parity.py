@@ -161,6 +161,27 @@ def test_conv3x3_stride2_kernel(ops, cin, cout, H, W):
         assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), flag
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(3, 16, 64, 30, 40), (5, 8, 32, 13, 22), (2, 24, 64, 7, 9), (64, 32, 64, 30, 40),
+                                            (1, 8, 64, 30, 40), (7, 12, 40, 15, 31)])
+def test_stride2_kernel_stacks_small_maps(ops, B, cin, cout, H, W):
+    """The stride-2 kernel puts 2 or 4 small images (H <= 2*rows - 1) into one 256-pixel tile (shared zero row); odd
+    batch sizes leave empty image slots in the last tile."""
+    g = torch.Generator().manual_seed(B * 10 + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, bias, stride=2, padding=1))
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV), stride=2)
+    keep, ops.S2_MIN_FILL = ops.S2_MIN_FILL, 0.0      # the stride-2 kernel whatever the fill
+    try:
+        assert pc.s2_tile(H, W) != 0
+        out = torch.full(ref.shape, 7.0, device=DEV)
+        ops.conv2d(x.to(DEV), pc, out, ops.ACT_RELU)
+    finally:
+        ops.S2_MIN_FILL = keep
+    assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), float((out.cpu() - ref).abs().max())
+
+
 @pytest.mark.parametrize("cin,cout,H,W,act", [(256, 7, 24, 40, 2), (256, 2, 24, 40, 0), (64, 5, 10, 14, 1), (100, 8, 6, 6, 0),
                                               (128, 64, 24, 40, 1), (192, 96, 12, 20, 0), (256, 7, 9, 11, 2)])
 def test_conv1x1_gemm_and_skinny_kernels(ops, cin, cout, H, W, act):
