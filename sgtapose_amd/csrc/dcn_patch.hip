@@ -277,6 +277,11 @@ static int launch_dcn_patch(DcnArgs& a, int tile, hipStream_t st) {
     if (tw == 1) return go(dcn_patch_kernel<2, 1, 16, R, CK, ACT>, 64, 1, 16);
     if (tw == 2) return go(dcn_patch_kernel<2, 1, 8, R, CK, ACT>, 64, 1, 8);
   }
+  if (mt == 4 && a.Cout_pad % 128 == 0) {            // 128 output channels per work-group: every gathered value feeds 4 MFMAs
+    if (tw == 0) return go(dcn_patch_kernel<4, 1, 32, R, CK, ACT>, 128, 1, 32);
+    if (tw == 1) return go(dcn_patch_kernel<4, 1, 16, R, CK, ACT>, 128, 1, 16);
+    if (tw == 2) return go(dcn_patch_kernel<4, 1, 8, R, CK, ACT>, 128, 1, 8);
+  }
   return SGTA_EBADARG;
 }
 

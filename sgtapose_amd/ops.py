@@ -160,16 +160,21 @@ class PackedConv:
             wd[:, :, :co] = w.reshape(co, ci // 4, 36).permute(1, 2, 0)
             self.wt_dcn8 = wd.contiguous()
 
-    def dcn_tile(self, H, W):
-        """(tile code, utilisation) of the best 128-pixel 2-D tile for sgta_dcnv2_lds_f32."""
-        mt = 2          # measured: 64 couts per work-group beats 128 (register pressure) on every DCN shape
+    def dcn_tile(self, H, W, B=1):
+        """(tile code, utilisation) of the best 128-pixel 2-D tile for sgta_dcnv2_lds_f32.  128 output channels per
+        work-group (every gathered sample feeds four MFMAs instead of two: -15 % at 128 -> 128 on 60x80 maps) where
+        that still leaves two rounds of work-groups; the small maps keep 64 (measured equal or slower with 128)."""
         best = None
         for code, tw in ((0, 32), (1, 16), (2, 8)):
             th = 128 // tw
-            util = (H * W) / float((-(-W // tw) * tw) * (-(-H // th) * th))
+            tiles = (-(-W // tw)) * (-(-H // th))
+            util = (H * W) / float(tiles * 128)
             if best is None or util > best[1] + 1e-9:
-                best = (mt * 10 + code, util)
-        return best
+                best = (code, util, tiles)
+        mt = 2
+        if DCN_MT == 4 and self.Cout_pad % 128 == 0 and B * best[2] * (self.Cout_pad // 128) >= DCN_MT4_MIN_WGS:
+            mt = 4
+        return (mt * 10 + best[0], best[1])
 
     def s2_tile(self, H, W):
         """Tile code for sgta_conv3x3s2_f32: best-filling 256-pixel output tile.  Inputs of at most 2*th/n - 1 rows are
@@ -358,6 +363,8 @@ def _splitk_ws(dev, nfloats):
 
 
 LINEAR_SPLITK_MAX_ROWS = 1024   # token GEMMs with at most this many rows may split K (0 disables)
+DCN_MT4_MIN_WGS = 1024         # work-groups a 128-channel DCN launch must still have (two rounds at 2 per CU)
+DCN_MT = 4                     # 4: 128 output channels per DCN work-group where it pays (dcn_tile), 2: always 64
 S2_MIN_FILL = 0.7              # minimum useful fraction of the stride-2 kernel's 256-pixel tiles
 WINO_TILE_OVERRIDE = None      # tests / tools: force the F(2x2,3x3) block shape (tile code 0..3)
 USE_WINO4 = True               # F(4x4,3x3) where the map fills its 64-tile blocks (else F(2x2,3x3))
@@ -433,7 +440,7 @@ def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     x, om, out = as_view(x), as_view(om), as_view(out)
     assert om.C == 27 and x.C == pc.Cin and out.C == pc.Cout
     if USE_DCN_LDS_KERNEL and pc.wt_dcn8 is not None and tile == 0:
-        code, _ = pc.dcn_tile(x.H, x.W)
+        code, _ = pc.dcn_tile(x.H, x.W, x.B)
         meta = None
         if _lib.PROFILE is not None:
             meta = _conv_meta(pc, out, 2, True)

@@ -264,6 +264,35 @@ def test_dcnv2_matches_oracle(ops, cin, cout, H, W, tile, off_scale):
     assert torch.allclose(out.cpu(), ref, atol=5e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,off_scale", [(32, 128, 17, 23, 1.0), (16, 256, 9, 40, 6.0), (64, 128, 24, 33, 0.3)])
+def test_dcnv2_128_channel_work_groups(ops, cin, cout, H, W, off_scale):
+    """The 128-output-channel form of the LDS-window kernel (every gathered sample feeds four MFMAs) against the
+    oracle and, bit for bit, against the 64-channel form (same per-channel arithmetic)."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    B = 2
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    omw = torch.randn(27, cin, 3, 3, generator=g) * (off_scale / (cin * 9) ** 0.5)
+    omb = torch.randn(27, generator=g) * 0.2
+    ref = oracle.dcn_v2_forward(x, w, b, omw, omb)
+    pc = ops.PackedConv(w.to(DEV), b.to(DEV), tap_major=True)
+    om = F.conv2d(x, omw, omb, padding=1).to(DEV)
+    outs = []
+    keep = (ops.DCN_MT, ops.DCN_MT4_MIN_WGS)
+    try:
+        for mt in (4, 2):
+            ops.DCN_MT, ops.DCN_MT4_MIN_WGS = mt, 0
+            assert pc.dcn_tile(H, W, B)[0] // 10 == mt
+            out = torch.full((B, cout, H, W), 7.0, device=DEV)
+            ops.dcn_v2(x.to(DEV), om, pc, out)
+            outs.append(out)
+    finally:
+        ops.DCN_MT, ops.DCN_MT4_MIN_WGS = keep
+    assert torch.equal(outs[0], outs[1])
+    assert torch.allclose(outs[0].cpu(), ref, atol=5e-5, rtol=1e-4)
+
+
 def test_dcn_module_zero_init_is_half_conv(ops):
     """Known answer: zero offset/mask conv -> 0.5 * conv3x3(x) + bias."""
     from sgtapose_amd.dcn_v2 import DCN
