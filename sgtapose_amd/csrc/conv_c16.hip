@@ -172,17 +172,21 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
     if (e < (NKI + NKH) * 4) reinterpret_cast<f32x4*>(As)[e] = wv[t];
   }
 
-  // this lane's window offset for every k-step (k = 4s + g)
-  int offi[SI], offh[SH];
-#pragma unroll
-  for (int s2 = 0; s2 < SI; ++s2) {
-    const int k = 4 * s2 + g, ch = k / KK, tap = k - ch * KK;
-    offi[s2] = k < 3 * KK ? ch * WSZ + (tap / KS) * WW + tap % KS : 0;      // k = 147: zero weight row
-  }
-#pragma unroll
-  for (int s2 = 0; s2 < SH; ++s2) {
-    const int k = 4 * s2 + g;
-    offh[s2] = k < KK ? 3 * WSZ + (k / KS) * WW + k % KS : 3 * WSZ;
+  // window offset of every (k-step, k-slot): k = 4s + g.  Built ONCE per work-group by 200 threads and read back from
+  // LDS in the loop -- each lane deriving its 50 offsets itself (k / 49, tap / 7, tap % 7) cost ~500 VALU instructions
+  // per thread beside the 200 MFMAs of a wave
+  __shared__ int offtab[(SI + SH) * 4];
+  if (tid < (SI + SH) * 4) {
+    const int s2 = tid >> 2, gg = tid & 3;
+    int o;
+    if (s2 < SI) {
+      const int k = 4 * s2 + gg, ch = k / KK, tap = k - ch * KK;
+      o = k < 3 * KK ? ch * WSZ + (tap / KS) * WW + tap % KS : 0;           // k = 147: zero weight row
+    } else {
+      const int k = 4 * (s2 - SI) + gg;
+      o = k < KK ? 3 * WSZ + (k / KS) * WW + k % KS : 3 * WSZ;
+    }
+    offtab[tid] = o;
   }
   int pix[4];
 #pragma unroll
@@ -197,16 +201,18 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
 #pragma unroll
   for (int s2 = 0; s2 < SI; ++s2) {
     const float av = As[(4 * s2 + g) * 16 + c16];
+    const float* wrow = win + offtab[4 * s2 + g];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
-      acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, win[offi[s2] + pix[n]], acc[0][n], 0, 0, 0);
+      acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[pix[n]], acc[0][n], 0, 0, 0);
   }
 #pragma unroll
   for (int s2 = 0; s2 < SH; ++s2) {
     const float av = As[(NKI + 4 * s2 + g) * 16 + c16];
+    const float* wrow = win + offtab[4 * (SI + s2) + g];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
-      acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, win[offh[s2] + pix[n]], acc[1][n], 0, 0, 0);
+      acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[pix[n]], acc[1][n], 0, 0, 0);
   }
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
