@@ -120,6 +120,92 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
   }
 }
 
+// ---- head_dim 4 (level 0: 1183 tokens per sample, the longest attention of the path) --------------------------------
+// With d = 4 the PV product fills 4 of the 16 MFMA rows, and a common running maximum across the four key groups of a
+// query costs two cross-lane exchanges per key tile.  Here every lane keeps its OWN online-softmax state (m, l, o[4])
+// over the keys it sees (j = 4g + r of every tile), PV is 16 plain FMAs on V rows broadcast from LDS, and the four
+// partial states of a query are merged once per query tile (log-sum-exp merge).  Same mathematics, different summation
+// order.  S^T = K Q^T stays on the MFMA.
+__global__ __launch_bounds__(256) void mhca4_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                    int ldk, const float* __restrict__ v, int ldv,
+                                                    const float* __restrict__ post, float* __restrict__ out, int ldo,
+                                                    int n, int npad, float inv_scale) {
+  constexpr int D = 4;
+  extern __shared__ float smem[];
+  const int ldt = npad + 4;
+  float* Kt = smem;                                // [4][ldt]   K transposed (MFMA A operand rows)
+  float* Vr = smem + D * ldt;                      // [npad][4]  V rows (one 16-byte broadcast read per key)
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  for (int j = tid; j < npad; j += 256) {
+    f32x4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (j < n) {
+      kv = *reinterpret_cast<const f32x4*>(k + ((long)b * n + j) * ldk + h * D);
+      vv = *reinterpret_cast<const f32x4*>(v + ((long)b * n + j) * ldv + h * D);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Kt[c * ldt + j] = kv[c];
+    *reinterpret_cast<f32x4*>(Vr + j * 4) = vv;
+  }
+  __syncthreads();
+  const int ntile = npad / 16;
+  for (int it = blockIdx.x * 4 + wave; it < ntile; it += gridDim.x * 4) {
+    const int i = it * 16 + li;
+    const int ic = i < n ? i : n - 1;
+    const float qf = q[((long)b * n + ic) * ldq + h * D + g];          // B[k = g][col = li]
+    const float* ptile = post + (((long)h * ntile + it) * ntile) * 256 + li * 16 + 4 * g;
+    float m = -INFINITY, lsum = 0.0f, o[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bias = *reinterpret_cast<const f32x4*>(ptile);
+    for (int jt = 0; jt < ntile; ++jt) {
+      f32x4 bias_nx = bias;
+      if (jt + 1 < ntile) bias_nx = *reinterpret_cast<const f32x4*>(ptile + (long)(jt + 1) * 256);
+      const float a = Kt[g * ldt + jt * 16 + li];                      // A[row = key li][k = g]
+      f32x4 s = {0, 0, 0, 0};
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf, s, 0, 0, 0);     // lane (li = query, g): keys jt*16 + 4g + r
+      float e[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], inv_scale, bias[r]);
+      const float mn = fmaxf(fmaxf(m, fmaxf(e[0], e[1])), fmaxf(e[2], e[3]));
+      // all four keys masked and nothing seen yet: keep the state empty (exp(-inf - -inf) would be NaN)
+      const float msafe = mn == -INFINITY ? 0.0f : mn;
+      const float alpha = __expf(m - msafe);
+      m = mn;
+      float p[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r] = __expf(e[r] - msafe);
+      lsum = fmaf(lsum, alpha, (p[0] + p[1]) + (p[2] + p[3]));
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) o[dd] *= alpha;
+      const float* vp = Vr + (jt * 16 + 4 * g) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + r * 4);  // V[key 4g + r][0..3], same address across li
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) o[dd] = fmaf(p[r], vv[dd], o[dd]);
+      }
+      bias = bias_nx;
+    }
+    // merge the four key groups of every query
+    float mall = fmaxf(m, __shfl_xor(m, 16));
+    mall = fmaxf(mall, __shfl_xor(mall, 32));
+    const float sc = m == -INFINITY ? 0.0f : __expf(m - mall);
+    lsum *= sc;
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {
+      o[dd] *= sc;
+      o[dd] += __shfl_xor(o[dd], 16);
+      o[dd] += __shfl_xor(o[dd], 32);
+    }
+    if (i < n && g == 0) {
+      const float inv = 1.0f / lsum;
+      *reinterpret_cast<f32x4*>(out + ((long)b * n + i) * ldo + h * D) = f32x4{o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+    }
+  }
+}
+
 static int mhca_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                        const float* pos_embed, const float* pos_tiles, float* out, int ldo, int B, int n, int n_heads,
                        int head_dim, hipStream_t st) {
@@ -133,6 +219,11 @@ static int mhca_launch(const float* q, int ldq, const float* k, int ldk, const f
   dim3 grid(qsplit, n_heads, B);
   const float inv = 1.0f / sqrtf((float)head_dim);
   size_t lds = (size_t)2 * head_dim * (npad + 4) * sizeof(float);
+  if (head_dim == 4 && pos_tiles && !(ldk & 3) && !(ldv & 3) && !(ldo & 3)) {
+    hipLaunchKernelGGL(mhca4_kernel, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_tiles, out, ldo, n, npad, inv);
+    SGTA_LAUNCH_CHECK();
+    return SGTA_OK;
+  }
   switch (head_dim) {
     case 4: hipLaunchKernelGGL(mhca_kernel<4>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
     case 8: hipLaunchKernelGGL(mhca_kernel<8>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;

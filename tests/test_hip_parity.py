@@ -379,17 +379,20 @@ def test_linear_with_relu_residual_layernorm(ops):
             assert torch.allclose(out.cpu(), F.layer_norm(ref + r, (N,), gm, bt, 1e-5), atol=5e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("n,d", [(63, 16), (343, 8), (1183, 4), (17, 4)])
+@pytest.mark.parametrize("n,d", [(63, 16), (343, 8), (1183, 4), (17, 4), (3, 4), (16, 4), (100, 4)])
 def test_attention_tiled_bias_equals_raw_bias(ops, n, d):
     """The structure-prior bias re-packed into 16 x 16 tiles (one 16-byte load per lane and key tile, padding mask
-    baked in) gives bit-identical attention outputs to the [heads, n, n] form."""
+    baked in) gives the attention outputs of the [heads, n, n] form (bit-identical where the kernel is the same)."""
     g = torch.Generator().manual_seed(n)
     B, hid = 2, 8 * d
     q, k, v = (torch.randn(B * n, hid, generator=g).to(DEV) for _ in range(3))
     pos = (torch.randn(8, n, n, generator=g) * 0.5).to(DEV)
     a = ops.mhca(q, k, v, pos, torch.empty(B * n, hid, device=DEV), B, n, 8, d)
     b = ops.mhca(q, k, v, ops.PosTiles(pos), torch.empty(B * n, hid, device=DEV), B, n, 8, d)
-    assert torch.equal(a, b)
+    if d == 4:       # head_dim 4 + tiled bias runs the per-lane-state kernel (VALU PV): same maths, other summation order
+        assert torch.allclose(a, b, atol=3e-6, rtol=1e-5), float((a - b).abs().max())
+    else:
+        assert torch.equal(a, b)
     s = (q.view(B, n, 8, d).permute(0, 2, 1, 3) @ k.view(B, n, 8, d).permute(0, 2, 3, 1)) / d ** 0.5 + pos
     ref = (torch.softmax(s, -1) @ v.view(B, n, 8, d).permute(0, 2, 1, 3)).permute(0, 2, 1, 3).reshape(B * n, hid)
     assert torch.allclose(a, ref, atol=2e-5, rtol=1e-4)
