@@ -109,6 +109,13 @@ int sgta_conv1x1_skinny_f32(const float* x, long x_bs, const float* w, const flo
 int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y, long y_bs,
                        int B, int Cin, int H, int W, int Cout, int Cout_pad, int tile, sgta_stream_t stream);
 
+/* The same convolution that also writes MaxPool2d(2, 2) of its output -- the ``bottom`` the following Tree takes of it
+ * (dla.py:218-223) -- to pool [B, Cout, Ho/2, Wo/2] (batch stride pool_bs; NULL: plain conv).  Needs the 8x32 output
+ * tile (tile % 10 == 0) and a map that is not stacked (H >= 16), else SGTA_EBADARG. */
+int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y, long y_bs,
+                            float* pool, long pool_bs, int B, int Cin, int H, int W, int Cout, int Cout_pad,
+                            int tile, sgta_stream_t stream);
+
 /* The 16-output-channel convs on the full-resolution maps (MFMA 16x16x4, whole input window + weights in LDS):
  *   mode 0: level0 = relu(bn(conv3x3(x [B,16,H,W])))                        (dla.py:246-247, :302-312); x2 = NULL
  *           wt [144][16] with k = c*9 + ky*3 + kx (BN scale folded), bias [16]

@@ -25,6 +25,7 @@ SIGNATURES = {
     "sgta_conv1x1_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_conv1x1_skinny_f32": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p],
     "sgta_conv3x3s2_f32": [_p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_conv3x3s2_pool_f32": [_p, _l, _p, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_dcnv2_fwd_f32": [_p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_dcnv2_lds_f32": [_p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_maxpool2_f32": [_p, _l, _p, _l, _i, _i, _i, _i, _p],

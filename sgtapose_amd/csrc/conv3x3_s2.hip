@@ -16,6 +16,7 @@ struct S2Args {
   int B, Cin, H, W, Ho, Wo, Cout, Cout_pad;
   int nchunks, tiles_x, tiles_y, n_ct, n_pt;
   int ni, thi;                     // ni > 1: a tile stacks ni images of thi output rows each (small maps)
+  float* pool; long pool_bs;       // TW == 32 only: MaxPool2d(2,2) of the output, [B, Cout, Ho/2, Wo/2] (nullptr: none)
 };
 
 __host__ __device__ constexpr int s2_wwp(int TW) { return TW == 8 ? 20 : (TW == 16 ? 40 : 2 * TW + 2); }
@@ -161,6 +162,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
     __syncthreads();
   }
 
+  if (TW == 32 && a.pool) {
+    // the 2x2 max-pool the next tree takes of this output (dla.py:218-223) rides along: with 32-wide tiles a lane's two
+    // accumulators are output rows 2w and 2w + 1 of the same column, the column pair is the neighbouring lane
+    const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
+    const bool pok = (l31 & 1) == 0 && oy[1] < a.Ho && ox[0] + 1 < a.Wo && (oy[0] & 1) == 0;
+    float* pb = a.pool + (long)ob[0] * a.pool_bs + (oy[0] >> 1) * Wp + (ox[0] >> 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = i * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+        const int co = ct * BM + cl;
+        float v = fmaxf(fmaxf(acc[i][0][r], acc[i][1][r]) + sbias[cl], 0.0f);
+        const float nb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v = fmaxf(v, nb);
+        if (pok && co < a.Cout) pb[(long)co * Hp * Wp] = v;
+      }
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     if (oy[j] >= a.Ho || ox[j] >= a.Wo) continue;
@@ -177,15 +196,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   }
 }
 
+extern "C" int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y,
+                                       long y_bs, float* pool, long pool_bs, int B, int Cin, int H, int W, int Cout,
+                                       int Cout_pad, int tile, hipStream_t st);
+
 extern "C" int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y,
                                   long y_bs, int B, int Cin, int H, int W, int Cout, int Cout_pad, int tile,
                                   hipStream_t st) {
+  return sgta_conv3x3s2_pool_f32(x, x_bs, wt, bias, y, y_bs, nullptr, 0, B, Cin, H, W, Cout, Cout_pad, tile, st);
+}
+
+// Same convolution that also writes MaxPool2d(2, 2) of its output (the ``bottom`` of the following Tree, dla.py:218-223)
+// to pool [B, Cout, Ho/2, Wo/2]; needs the 8x32 output tile (tile % 10 == 0) and an un-stacked map, else SGTA_EBADARG.
+extern "C" int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* wt, const float* bias, float* y,
+                                       long y_bs, float* pool, long pool_bs, int B, int Cin, int H, int W, int Cout,
+                                       int Cout_pad, int tile, hipStream_t st) {
   if (!x || !wt || !bias || !y || B <= 0 || Cin <= 0 || H < 2 || W < 2 || Cout <= 0) return SGTA_EBADARG;
+  if (pool && tile % 10 != 0) return SGTA_EBADARG;
   if (Cin % 4 || Cout_pad % 32 || Cout_pad < Cout || (long)Cin * H * W > 0x7fffffffL) return SGTA_EBADARG;
   S2Args a{};
   a.x = x; a.x_bs = x_bs; a.wt = wt; a.bias = bias; a.y = y; a.y_bs = y_bs;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
   a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 4;
+  a.pool = pool; a.pool_bs = pool_bs;
   auto go = [&](auto kern, int BM, int TW) -> int {
     const int TH = 256 / TW;
     a.n_ct = a.Cout_pad / BM;
@@ -202,6 +235,7 @@ extern "C" int sgta_conv3x3s2_f32(const float* x, long x_bs, const float* wt, co
         a.n_pt = cdiv(a.B, n) * a.tiles_x;
         break;
       }
+    if (a.pool && a.ni > 1) return SGTA_EBADARG;     // pooled rows would straddle stacked images
     int grid = cdiv(a.n_pt, 8) * 8 * a.n_ct;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
     SGTA_LAUNCH_CHECK();

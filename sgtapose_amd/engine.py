@@ -160,12 +160,14 @@ class Engine:
         ops.conv2d(cat, P[name + ".root"], out, ACT_RELU)
         return out
 
-    def _tree(self, node, name, x, out):
+    def _tree(self, node, name, x, out, bottom=None):
         N, c, cin = x.B, node.cout, node.cin
         h, w = x.H // node.stride, x.W // node.stride
         if node.levels == 1:
             cat = self.vbuf(name + ".cat", N, node.root_dim, h, w)
-            return self._tree_l1(node, name, x, out, cat)
+            if bottom is not None and node.level_root:       # a pre-pooled input must sit in the Root's concat slot
+                bottom = None
+            return self._tree_l1(node, name, x, out, cat, bottom=bottom)
         # 2-level, level-root node (levels 3, 4): inner Root sees [x2 | x1 | bottom | tree1-out]
         inner = node.tree2
         cat2 = self.vbuf(name + ".cat2", N, inner.root_dim, h, w)
@@ -205,13 +207,18 @@ class Engine:
         if after_level:
             after_level(0, lv[0])
         lv.append(self.vbuf("l1", N, 32, H // 2, W // 2))
-        ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
+        # level2 = Tree(levels = 1): its ``bottom`` = MaxPool2d(2)(level1 output) rides in the stride-2 kernel's epilogue
+        pooled = self.vbuf("pool", N, 32, H // 4, W // 4)
+        if not ops.conv3x3s2_pool(lv[0], P["level1"], lv[1], pooled):
+            ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
+            pooled = None
         if after_level:
             after_level(1, lv[1])
         ch = self.model.base.channels
         for i in range(2, 6):
             out = self.vbuf("l%d" % i, N, ch[i], H >> i, W >> i)
-            self._tree(getattr(self.model.base, "level%d" % i), "level%d" % i, lv[i - 1], out)
+            self._tree(getattr(self.model.base, "level%d" % i), "level%d" % i, lv[i - 1], out,
+                       bottom=pooled if i == 2 else None)
             lv.append(out)
             if after_level:
                 after_level(i, out)

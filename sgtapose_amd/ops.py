@@ -435,6 +435,25 @@ def conv_c16(x, x2, pc, out):
     return out
 
 
+def conv3x3s2_pool(x, pc, out, pool):
+    """relu(bn(conv3x3 stride 2)) -> out AND MaxPool2d(2,2)(out) -> pool in one launch when the stride-2 kernel takes the
+    layer with its 8x32 tile; returns False (nothing done) otherwise."""
+    x, out, pool = as_view(x), as_view(out), as_view(pool)
+    if not (USE_S2_KERNEL and pc.ks == 3 and pc.stride == 2 and pc.wt_s2 is not None and x.H >= 16):
+        return False
+    code = pc.s2_tile(x.H, x.W)
+    if code == 0 or code % 10 != 0:
+        return False
+    assert pool.B == out.B and pool.C == out.C and pool.H == out.H // 2 and pool.W == out.W // 2
+    meta = None
+    if _lib.PROFILE is not None:
+        meta = _conv_meta(pc, out, 2, False)
+        meta["kernel"] = "conv3x3_s2_kernel<%d,%d>" % (code // 10, 32)
+    _lib.call("sgta_conv3x3s2_pool_f32", x.ptr, x.bs, pc.wt_s2.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
+              pool.ptr, pool.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, code, _stream(), meta=meta)
+    return True
+
+
 def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     """Fused modulated deformable conv: ``om`` is the raw 27-channel offset/mask conv output."""
     x, om, out = as_view(x), as_view(om), as_view(out)

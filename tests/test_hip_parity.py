@@ -161,6 +161,29 @@ def test_conv3x3_stride2_kernel(ops, cin, cout, H, W):
         assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5), flag
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 16, 32, 48, 128), (3, 8, 64, 34, 70), (1, 16, 40, 16, 66)])
+def test_stride2_kernel_with_fused_maxpool(ops, B, cin, cout, H, W):
+    """level1's conv also emits MaxPool2d(2,2) of its output (the next Tree's ``bottom``, dla.py:218-223): both outputs
+    against torch, incl. odd output sizes (the pool floors) and partial tiles."""
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, bias, stride=2, padding=1))
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV), stride=2)
+    keep, ops.S2_MIN_FILL = ops.S2_MIN_FILL, 0.0
+    try:
+        out = torch.full(ref.shape, 7.0, device=DEV)
+        pool = torch.full((B, cout, ref.shape[2] // 2, ref.shape[3] // 2), 7.0, device=DEV)
+        fused = ops.conv3x3s2_pool(x.to(DEV), pc, out, pool)
+    finally:
+        ops.S2_MIN_FILL = keep
+    if not fused:
+        pytest.skip("the 8x32 tile is not the best fit for this map")
+    assert torch.allclose(out.cpu(), ref, atol=3e-5, rtol=1e-5)
+    assert torch.equal(pool, F.max_pool2d(out, 2, 2))
+
+
 @pytest.mark.parametrize("B,cin,cout,H,W", [(3, 16, 64, 30, 40), (5, 8, 32, 13, 22), (2, 24, 64, 7, 9), (64, 32, 64, 30, 40),
                                             (1, 8, 64, 30, 40), (7, 12, 40, 15, 31)])
 def test_stride2_kernel_stacks_small_maps(ops, B, cin, cout, H, W):
