@@ -178,9 +178,20 @@ __global__ __launch_bounds__(256) void gauss_peaks_kernel(const float* __restric
   double wr[GRADIUS + 1];
 #pragma unroll
   for (int j = 0; j <= GRADIUS; ++j) wr[j] = w[j];
-  for (int e = threadIdx.x; e < (GP_TH + 26) * W; e += 256) {
-    const int k = e / W, x = e - k * W;
-    sin[e] = src[(long)reflect_idx(y0 - 13 + k, H) * W + x];
+  // eight loads in flight per thread (a one-load-per-iteration loop waited a full memory round trip 31 times: 100 of
+  // the kernel's 133 us)
+  const int nin = (GP_TH + 26) * W;
+  for (int e0 = threadIdx.x; e0 < nin; e0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256;
+      const int k = e / W, x = e - k * W;
+      v[u] = e < nin ? src[(long)reflect_idx(y0 - 13 + k, H) * W + x] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * 256 < nin) sin[e0 + u * 256] = v[u];
   }
   __syncthreads();
   // vertical pass: output row yy = y0 - 1 + k reads input rows yy - 12 .. yy + 12 = LDS rows k .. k + 24
