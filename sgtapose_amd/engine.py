@@ -249,7 +249,6 @@ class Engine:
             q = self.buf("q%d" % i, (M, hid))
             att = self.buf("att%d" % i, (M, hid))
             y1 = self.buf("y1_%d" % i, (M, C))
-            hdn = self.buf("ffn%d" % i, (M, D_FFN))
             nxt = self.buf("qry_b%d" % i, (M, C))
             for it in range(3):                    # ONE shared layer, three times (dla.py:788-803)
                 ops.linear(cur, T["wq"], None, q)
@@ -257,6 +256,7 @@ class Engine:
                 ops.linear(att, T["fc_w"], T["fc_b"], y1, res=cur, ln=T["ln1"])
                 dst = cat_tok[:, :C] if it == 2 else nxt
                 if ops.ffn_ln(y1, T["w1"], T["b1"], T["w2"], T["b2"], T["ln3"], dst) is None:
+                    hdn = self.buf("ffn%d" % i, (M, D_FFN))        # two-launch fall-back only: 155 MB at level 0
                     ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
                     ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
                 cur, nxt = dst, cur

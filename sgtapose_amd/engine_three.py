@@ -37,7 +37,6 @@ class EngineThree(Engine):
         q = self.buf("q%s%d" % (tag, i), (M, hid))
         att = self.buf("att%s%d" % (tag, i), (M, hid))
         y1 = self.buf("y1%s%d" % (tag, i), (M, C))
-        hdn = self.buf("ffn%s%d" % (tag, i), (M, D_FFN))
         nxt = [self.buf("qa%s%d" % (tag, i), (M, C)), self.buf("qb%s%d" % (tag, i), (M, C))]
         cur = qry
         for it in range(3):
@@ -46,6 +45,7 @@ class EngineThree(Engine):
             ops.linear(att, T["fc_w"], T["fc_b"], y1, res=cur, ln=T["ln1"])
             dst = out if it == 2 else nxt[it]
             if ops.ffn_ln(y1, T["w1"], T["b1"], T["w2"], T["b2"], T["ln3"], dst) is None:
+                hdn = self.buf("ffn%s%d" % (tag, i), (M, D_FFN))   # two-launch fall-back only
                 ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
                 ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
             cur = dst
