@@ -50,9 +50,9 @@ class EngineThree(Engine):
                 ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
             cur = dst
 
-    def temporal_three(self, lv, idx_pp, idx_p, B):
+    def temporal_three(self, lv, idx_pp, idx_p, B, levels=range(6)):
         K = self.num_classes
-        for i in range(6):
+        for i in levels:
             feats = lv[i]
             C, H, W = feats.C, feats.H, feats.W
             pp_f, pre_f, cur_f = View(feats.base[:B]), View(feats.base[B:2 * B]), View(feats.base[2 * B:])
@@ -104,8 +104,21 @@ class EngineThree(Engine):
             idx_pp = ops.prior_argmax(ppre_hm_cls, repro_hm_cls, self.buf("idxpp", (2, B, K, 2)))
             idx_p = ops.prior_argmax(pre_hm_cls, repro_hm_cls, self.buf("idx", (2, B, K, 2)))
             lv = self.backbone_frames(((ppre_img, ppre_hm), (pre_img, pre_hm), (x, repro_hm)))
-            self.temporal_three(lv, idx_pp, idx_p, B)
+            # levels 0 / 1 never reach the heads (dla_up starts at level 2) and their stage is a chain of small
+            # latency-bound kernels: it runs on a side stream beside the matrix-bound rest of the step (engine.py)
+            main = torch.cuda.current_stream()
+            side = self._side_stream() if (self.use_side_stream and _lib.PROFILE is None and self.compute_dead_levels) else None
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self.temporal_three(lv, idx_pp, idx_p, B, (0, 1))
+                self.temporal_three(lv, idx_pp, idx_p, B, (2, 3, 4, 5))
+            else:
+                self.temporal_three(lv, idx_pp, idx_p, B, range(6) if self.compute_dead_levels else (2, 3, 4, 5))
             cur = [View(v.base[2 * B:]) for v in lv]
             feat = self.neck(cur)
             self.last_feat = feat
-            return self.heads(feat, hm_act, static)
+            out = self.heads(feat, hm_act, static)
+            if side is not None:
+                main.wait_stream(side)             # the step is complete only when the side work is
+            return out
