@@ -67,7 +67,10 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 
 // NCG = output-channel groups (of 16) per work-group: 1 -> 4 waves, two work-groups per CU; 2 -> 8 waves, one work-group
 // per CU whose two channel groups share the staged window (35 % fewer bytes through the memory pipeline per MFMA).
-template <int TC, int ACT, int RES, int NCG>
+// URC > 0: the transformed weights of ALL URC chunks (Cin = 4 * URC, one channel-group item stream: n_ct == 1) stay
+// resident in LDS beside the window ring -- a shallow layer (level0: 16 -> 16 at full resolution) otherwise re-streams
+// its 74 KB of U for every 32x32-pixel item, 44 % of the bytes it moves
+template <int TC, int ACT, int RES, int NCG, int URC = 0>
 __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_kernel(Wino4Args a) {
   constexpr int NT = 256 * NCG, BM = 16 * NCG, CK = 4, TR = 64 / TC, EDGE = TC < 16 ? TC : 16;
   // channel plane stride == 0 (mod 64 floats = one 256-byte bank row): ds_read_b128 is served in four 16-lane groups
@@ -78,8 +81,9 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
   constexpr int P_SLOTS = CK * WQ, P_PER = (P_SLOTS + NT - 1) / NT;        // 16-byte window slots per stage
   constexpr int LDU = 36, U_F = CK * BM * LDU, U_SLOTS = U_F / 4, U_PER = (U_SLOTS + NT - 1) / NT;
   static_assert(P_SLOTS >= NT && U_SLOTS >= NT, "a DMA round must be full");
-  constexpr int STAGE = P_SLOTS * 4 + U_F;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int P_F = P_SLOTS * 4;
+  constexpr int STAGE = URC ? P_F : P_F + U_F;                            // ring slot: window (+ U unless resident)
+  __shared__ __attribute__((aligned(16))) float lds[URC ? 2 * P_F + URC * U_F : 2 * STAGE];
 
   // persistent work-groups, XCD-contiguous logical ids, channel group fastest (see conv3x3_wino.hip)
   const int G = gridDim.x;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
   const int trow = t / TC, tcol = t % TC;
   const bool edge_l = (tl % EDGE) == 0, edge_r = (tl % EDGE) == EDGE - 1;
   const int poffl = g * WSZ + (4 * trow) * WWL + 4 * tcol + 4;            // middle quad of the lane's first row
-  const int uoffl = CK * WSZ + (g * BM + cg * 16 + tl) * LDU;
+  const int uoffl = (URC ? 2 * P_F : P_F) + (g * BM + cg * 16 + tl) * LDU;   // resident: behind both window slots
 
   // ---- buffer LDS-DMA staging (16-byte slots; out-of-image slots carry an out-of-range offset -> zeros) ------
   unsigned poff[P_PER], uoff[U_PER];
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + (q < P_PER - 1 ? q * NT * 4 : P_SLOTS * 4 - NT * 4)),
                                                  16, poff[q], kc * CK * HW * 4, 0, 0);
     } else {
-      float* udst = lds + st * STAGE + P_SLOTS * 4 + wave * 256;
+      float* udst = lds + (URC ? 2 * P_F + kc * U_F : st * STAGE + P_F) + wave * 256;
 #pragma unroll
       for (int q = 0; q < U_PER; ++q)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(urs, (lds_ptr_t)(udst + (q < U_PER - 1 ? q * NT * 4 : U_SLOTS * 4 - NT * 4)),
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
   int item = wg, sidx = 0;
   setup(item);
   stage(0, 0, 0); stage(0, 0, 1);
+  if (URC)
+    for (int kc = 1; kc < URC; ++kc) stage(kc, 0, 1);           // every chunk's U, once per work-group
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
       }
       if (more) stage(nkc, sidx ^ 1, 0);
       const float* wp = lds + sidx * STAGE + poffl;
-      const float* up = lds + sidx * STAGE + uoffl;
+      const float* up = lds + (URC ? kc * U_F : sidx * STAGE) + uoffl;
       // raw 6x6 window: middle four columns from LDS, outer two from the neighbouring lanes' quads
       f32x4 mid[6];
 #pragma unroll
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int v = 0; v < 4; ++v) u1[v] = *reinterpret_cast<const f32x4*>(up + 20 + v * 4);
-      if (more) stage(nkc, sidx ^ 1, 1);
+      if (more && !URC) stage(nkc, sidx ^ 1, 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 12; p < 20; ++p)
@@ -323,6 +329,8 @@ static int launch_wino4(Wino4Args& a, int tile, hipStream_t st) {
     return SGTA_OK;
   };
   // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 4x4 output tiles
+  if (NCG == 2 && ACT == 1 && RES == 0 && tile == 0 && a.Cin == 16 && a.Cout_pad == 32)
+    return go(conv3x3_wino4_kernel<32, 1, 0, 2, 4>, 32);   // shallow full-resolution layer: U resident in LDS
   switch (tile) {
     case 0: return go(conv3x3_wino4_kernel<32, ACT, RES, NCG>, 32);
     case 1: return go(conv3x3_wino4_kernel<16, ACT, RES, NCG>, 16);

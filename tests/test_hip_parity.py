@@ -60,7 +60,8 @@ def test_conv2d_bn_relu_residual(ops, cin, cout, ks, stride, tile):
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 24, 40), (128, 27, 15, 20), (16, 96, 17, 23), (64, 768, 8, 12), (512, 512, 15, 20),
-                                          (32, 64, 5, 130), (24, 40, 64, 6), (8, 16, 64, 16), (24, 48, 30, 132), (64, 64, 34, 36)])
+                                          (32, 64, 5, 130), (24, 40, 64, 6), (8, 16, 64, 16), (24, 48, 30, 132), (64, 64, 34, 36),
+                                          (16, 16, 64, 256), (16, 16, 40, 36), (16, 27, 24, 132)])
 def test_conv3x3_implementations_agree(ops, cin, cout, H, W):
     """Winograd F(2x2,3x3), the LDS-range direct kernel and the generic implicit GEMM against torch,
     incl. odd map sizes (partial 2x2 tiles), residual + ReLU, and a non-multiple-of-32 Cout."""
