@@ -180,6 +180,9 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
         bsv = *reinterpret_cast<const f32x4*>(a.bias + ct * BM + cg * 16 + 4 * g);
       }
       if (more) stage(nkc, sidx ^ 1, 0);
+      // resident-U form: a channel group that is all padding (level0: 16 real output channels in a 32-wide group) only
+      // stages and synchronises -- its MFMAs would take the matrix pipe from the wave it shares a SIMD with
+      if (!(URC && cg * 16 >= a.Cout)) {
       const float* wp = lds + sidx * STAGE + poffl;
       const float* up = lds + (URC ? kc * U_F : sidx * STAGE) + uoffl;
       // raw 6x6 window: middle four columns from LDS, outer two from the neighbouring lanes' quads
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino4_ker
 #pragma unroll
       for (int p = 20; p < 36; ++p)
         acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[(p - 20) >> 2][p & 3], V[p], acc[p], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // every LDS read of this stage has returned; the next chunk has landed once all waves pass the barrier
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
