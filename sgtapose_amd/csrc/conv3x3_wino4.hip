@@ -333,8 +333,31 @@ static int launch_wino4(Wino4Args& a, int tile, hipStream_t st) {
     return SGTA_OK;
   };
   // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 4x4 output tiles
-  if (NCG == 2 && ACT == 1 && RES == 0 && tile == 0 && a.Cin == 16 && a.Cout_pad == 32)
+  if (NCG == 2 && ACT == 1 && RES == 0 && tile == 0 && a.Cin == 16 && a.Cout_pad == 32) {
+    static const int l0 = getenv("SGTA_L0_FORM") ? atoi(getenv("SGTA_L0_FORM")) : 1;
+    if (l0 == 1 && a.Cout <= 16) {
+      // 4-wave work-groups of 16 output channels, two per CU (16x64-pixel blocks keep ring + resident U under 80 KB):
+      // no idle channel group, 0.62-0.66 ms against 0.72 for the 8-wave form (SGTA_L0_FORM=0) on level0
+      auto go1 = [&](auto kern, int TC) -> int {
+        const int TR = 64 / TC;
+        a.n_ct = 1;
+        a.blk_r = cdiv(cdiv(a.H, 4), TR);
+        a.blk_c = cdiv(cdiv(a.W, 4), TC);
+        a.n_pt = a.B * a.blk_r * a.blk_c;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+          return SGTA_EBADARG;
+        const long items = a.n_pt;
+        int grid = (int)(items < 2L * cus ? items : 2L * cus);
+        grid = cdiv(grid, 8) * 8;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, a);
+        SGTA_LAUNCH_CHECK();
+        return SGTA_OK;
+      };
+      return go1(conv3x3_wino4_kernel<16, 1, 0, 1, 4>, 16);
+    }
     return go(conv3x3_wino4_kernel<32, 1, 0, 2, 4>, 32);   // shallow full-resolution layer: U resident in LDS
+  }
   switch (tile) {
     case 0: return go(conv3x3_wino4_kernel<32, ACT, RES, NCG>, 32);
     case 1: return go(conv3x3_wino4_kernel<16, ACT, RES, NCG>, 16);
