@@ -7,6 +7,7 @@
 // neighbouring output pixels become unit-stride and conflict-free.  Lane half = channel of a pair, the nine
 // k-steps of a pair are the taps (as in conv3x3_patch.hip).
 #include "common.h"
+#include <cstdlib>
 
 struct S2Args {
   const float* x;  long x_bs;
@@ -21,17 +22,22 @@ struct S2Args {
 
 __host__ __device__ constexpr int s2_wwp(int TW) { return TW == 8 ? 20 : (TW == 16 ? 40 : 2 * TW + 2); }
 
-template <int MT, int TW>
+// VEC: the window is staged in its NATURAL column order by 16-byte DMA (origin 4 columns left of the tile: rows of
+// 2*TW + 8 floats, W % 4 == 0) -- 3.6x fewer DMA instructions than 4-byte de-interleaved slots; the stride-2 reads of
+// neighbouring output pixels then hit each bank twice, which the HBM-bound shallow layers do not notice
+template <int MT, int TW, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   constexpr int NT = 2, BM = MT * 32, TH = 256 / TW, CK = 4;
-  constexpr int WH = 2 * TH + 1, WW = 2 * TW + 1, NE = TW + 1, WWP = s2_wwp(TW), WSZ = WH * WWP;
+  constexpr int WH = 2 * TH + 1, WW = 2 * TW + 1, NE = TW + 1, WWP = VEC ? 2 * TW + 8 : s2_wwp(TW), WSZ = WH * WWP;
   constexpr int KC = CK * 9;
   // weights: k-major rows As[k][BM] (a lane's A operand = consecutive output channels: conflict-free), staged by
   // 16-byte LDS-DMA; window: 4-byte slots (de-interleaved columns)
-  constexpr int P_TOT = CK * WSZ, A_SLOTS = KC * BM / 4;
+  constexpr int P_TOT = VEC ? CK * WSZ / 4 : CK * WSZ, A_SLOTS = KC * BM / 4;       // window slots: quads / floats
   constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_SLOTS + 255) / 256;
+  constexpr int P_FL = VEC ? P_PER * 1024 : P_PER * 256;                           // floats of a stage's window part
   static_assert(A_SLOTS >= 256, "weight tile smaller than one DMA round");
-  constexpr int STAGE = P_PER * 256 + KC * BM;
+  static_assert(!VEC || (CK * WSZ) % 4 == 0, "quad slots");
+  constexpr int STAGE = P_FL + KC * BM;
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + BM];
   float* const sbias = lds + 2 * STAGE;
 
@@ -59,13 +65,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
 #pragma unroll
   for (int t = 0; t < P_PER; ++t) {
     const int e = tid + t * 256;
-    const int c = e / WSZ, r = e - c * WSZ;
-    const int sx = r % WWP;
-    const int col = sx < NE ? 2 * sx : 2 * (sx - NE) + 1;
-    const int wr = r / WWP, gx = wx0 + col;
+    int c, wr, gx;
+    bool ok;
+    if (VEC) {                                       // slot = 16-byte quad of a natural-order row
+      constexpr int QR = WWP / 4, QC = WSZ / 4;
+      c = e / QC;
+      const int r = e - c * QC;
+      wr = r / QR;
+      gx = 2 * tx0 - 4 + 4 * (r - wr * QR);
+      ok = e < P_TOT && (unsigned)gx < (unsigned)W;
+    } else {
+      c = e / WSZ;
+      const int r = e - c * WSZ;
+      const int sx = r % WWP;
+      const int col = sx < NE ? 2 * sx : 2 * (sx - NE) + 1;
+      wr = r / WWP;
+      gx = wx0 + col;
+      ok = e < P_TOT && sx < WW && (unsigned)gx < (unsigned)W;
+    }
     int gy = wy0 + wr;
     long img = 0;
-    bool ok = e < P_TOT && sx < WW && (unsigned)gx < (unsigned)W;
     if (stacked) {
       const int si = wr / (2 * a.thi);
       gy = wr - si * 2 * a.thi - 1;
@@ -93,10 +112,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
   auto stage = [&](int kc, int st) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float* dst = lds + st * STAGE + wave * 64;
+    float* dst4 = lds + st * STAGE + wave * 256;
 #pragma unroll
     for (int t = 0; t < P_PER; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 256), 4, poff[t], kc * CK * HW * 4, 0, 0);
-    float* adst = lds + st * STAGE + P_PER * 256 + wave * 256;
+      if (VEC) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst4 + t * 1024), 16, poff[t], kc * CK * HW * 4, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 256), 4, poff[t], kc * CK * HW * 4, 0, 0);
+    float* adst = lds + st * STAGE + P_FL + wave * 256;
 #pragma unroll
     for (int t = 0; t < A_PER; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + (t < A_PER - 1 ? t * 1024 : A_SLOTS * 4 - 1024)), 16,
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
       oy[j] = ob[j] < a.B ? ty - si * a.thi : a.Ho;  // image slots beyond the batch store nothing
       if (ob[j] >= a.B) ob[j] = a.B - 1;
     }
-    tbase[j] = (2 * ty) * WWP + tx;
+    tbase[j] = VEC ? (2 * ty) * WWP + 2 * tx + 3 : (2 * ty) * WWP + tx;
   }
 
   f32x16 acc[MT][NT];
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
     const int st = kc & 1;
     if (kc + 1 < a.nchunks) stage(kc + 1, st ^ 1);
     const float* win = lds + st * STAGE;
-    const float* As = win + P_PER * 256;
+    const float* As = win + P_FL;
 #pragma unroll
     for (int q = 0; q < CK / 2; ++q) {
       const float* prow = win + (2 * q + lh) * WSZ;
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_s2_kernel(S2Args a) {
       for (int tap = 0; tap < 9; ++tap) {
         constexpr int dummy = 0; (void)dummy;
         const int ky = tap / 3, kx = tap % 3;
-        const int toff = ky * WWP + (kx & 1) * NE + (kx >> 1);
+        const int toff = VEC ? ky * WWP + kx : ky * WWP + (kx & 1) * NE + (kx >> 1);
         float av[MT], bv[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) av[i] = arow[tap * BM + i * 32];
@@ -243,15 +264,18 @@ extern "C" int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* w
   };
   // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2} = 8x32 / 16x16 / 32x8 output tiles
   const int mt = tile / 10, tw = tile % 10;
+  // 16-byte window DMA where rows and planes are 16-byte aligned (SGTA_S2_VEC=0 keeps the 4-byte de-interleaved form)
+  static const bool allow_vec = !(getenv("SGTA_S2_VEC") && atoi(getenv("SGTA_S2_VEC")) == 0);
+  const bool vec = allow_vec && W % 4 == 0 && x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && tw == 0;
   if (mt == 2 && Cout_pad % 64 == 0) {
-    if (tw == 0) return go(conv3x3_s2_kernel<2, 32>, 64, 32);
-    if (tw == 1) return go(conv3x3_s2_kernel<2, 16>, 64, 16);
-    if (tw == 2) return go(conv3x3_s2_kernel<2, 8>, 64, 8);
+    if (tw == 0) return vec ? go(conv3x3_s2_kernel<2, 32, true>, 64, 32) : go(conv3x3_s2_kernel<2, 32, false>, 64, 32);
+    if (tw == 1) return go(conv3x3_s2_kernel<2, 16, false>, 64, 16);
+    if (tw == 2) return go(conv3x3_s2_kernel<2, 8, false>, 64, 8);
   }
   if (mt == 1) {
-    if (tw == 0) return go(conv3x3_s2_kernel<1, 32>, 32, 32);
-    if (tw == 1) return go(conv3x3_s2_kernel<1, 16>, 32, 16);
-    if (tw == 2) return go(conv3x3_s2_kernel<1, 8>, 32, 8);
+    if (tw == 0) return vec ? go(conv3x3_s2_kernel<1, 32, true>, 32, 32) : go(conv3x3_s2_kernel<1, 32, false>, 32, 32);
+    if (tw == 1) return go(conv3x3_s2_kernel<1, 16, false>, 32, 16);
+    if (tw == 2) return go(conv3x3_s2_kernel<1, 8, false>, 32, 8);
   }
   return SGTA_EBADARG;
 }
