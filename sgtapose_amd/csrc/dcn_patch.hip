@@ -12,6 +12,7 @@
 // channel pair (lane half 0/1 = channel 2q/2q+1 of the MFMA k-slot).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 struct DcnArgs {
   const float* x;  long x_bs;
@@ -24,18 +25,24 @@ struct DcnArgs {
 };
 
 
-template <int MT, int NT, int TW, int R, int CK, int ACT>
+// VEC: window origin 8 columns left of the tile (16-byte aligned rows of TW + 16 floats, W % 4 == 0) staged by 16-byte
+// DMA -- 3-4 DMA instructions per chunk and wave instead of 9-11; the two extra halo columns per side also widen the
+// range of offsets that stay on the fast path
+template <int MT, int NT, int TW, int R, int CK, int ACT, bool VEC>
 __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
   constexpr int BM = MT * 32, TH = 128 * NT / TW;
-  constexpr int PH = TH + 2 * R, PW = TW + 2 * R, PSZ = PH * PW;
+  constexpr int RX = VEC ? 8 : R;
+  constexpr int PH = TH + 2 * R, PW = TW + 2 * RX, PSZ = PH * PW;
   constexpr int KC = CK * 9;
   // weights: k-major rows As[k][BM] (a lane's A operand = consecutive output channels: conflict-free), staged
   // by 16-byte LDS-DMA; window: 4-byte LDS-DMA slots (arbitrary alignment of the image rows)
-  constexpr int P_TOT = CK * PSZ, A_SLOTS = KC * BM / 4;
+  constexpr int P_TOT = VEC ? CK * PSZ / 4 : CK * PSZ, A_SLOTS = KC * BM / 4;      // window slots: quads / floats
   constexpr int P_PER = (P_TOT + 255) / 256, A_PER = (A_SLOTS + 255) / 256;
+  constexpr int P_FL = VEC ? P_PER * 1024 : P_PER * 256;                          // floats of a stage's window part
   static_assert(A_SLOTS >= 256, "weight tile smaller than one DMA round");
+  static_assert(!VEC || PW % 4 == 0, "quad rows");
   // ONE shared array (a second object beside an LDS-DMA target makes hipcc drain vmcnt early)
-  constexpr int STAGE = P_PER * 256 + KC * BM;                // floats per stage
+  constexpr int STAGE = P_FL + KC * BM;                       // floats per stage
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + BM];
   float* const sbias = lds + 2 * STAGE;
 
@@ -50,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
   const int b = pt / tiles;
   const int tr = pt - b * tiles;
   const int ty0 = (tr / a.tiles_x) * TH, tx0 = (tr % a.tiles_x) * TW;
-  const int win_y = ty0 - R, win_x = tx0 - R;    // window origin (may be negative)
+  const int win_y = ty0 - R, win_x = tx0 - RX;   // window origin (may be negative)
   const float* xb = a.x + (long)b * a.x_bs;
   if (tid < BM) sbias[tid] = a.bias[ct * BM + tid];
 
@@ -61,8 +68,10 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
 #pragma unroll
   for (int t = 0; t < P_PER; ++t) {
     const int e = tid + t * 256;
-    const int c = e / PSZ, r = e - c * PSZ;
+    const int ef = VEC ? e * 4 : e;                 // first float of the slot
+    const int c = ef / PSZ, r = ef - c * PSZ;
     const int gy = win_y + r / PW, gx = win_x + r % PW;
+    // VEC: gx is a multiple of 4 and W % 4 == 0, so a quad is inside the row or outside it as a whole
     const bool ok = e < P_TOT && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     poff[t] = ok ? (unsigned)(c * HW + gy * W + gx) * 4u : 0x80000000u;
   }
@@ -84,13 +93,14 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
   // part 0 / 1: first / second half of the window slots, part 2: weights (spread between the k-steps)
   auto stage = [&](int kc, int st, int part) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    float* dst = lds + st * STAGE + wave * 64;
+    float* dst = lds + st * STAGE + (VEC ? wave * 256 : wave * 64);
     if (part < 2) {
 #pragma unroll
       for (int t = part * ((P_PER + 1) / 2); t < (part ? P_PER : (P_PER + 1) / 2); ++t)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 256), 4, poff[t], kc * CK * HW * 4, 0, 0);
+        if (VEC) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 1024), 16, poff[t], kc * CK * HW * 4, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + t * 256), 4, poff[t], kc * CK * HW * 4, 0, 0);
     } else {
-      float* adst = lds + st * STAGE + P_PER * 256 + wave * 256;
+      float* adst = lds + st * STAGE + P_FL + wave * 256;
 #pragma unroll
       for (int t = 0; t < A_PER; ++t)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + (t < A_PER - 1 ? t * 1024 : A_SLOTS * 4 - 1024)),
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void dcn_patch_kernel(DcnArgs a) {
     const bool more = kc + 1 < a.nchunks;
     if (more) stage(kc + 1, st ^ 1, 0);            // async: lands in the other stage during the MFMAs
     const float* patch = lds + st * STAGE;
-    const float* Asm = patch + P_PER * 256;
+    const float* Asm = patch + P_FL;
     const float* xc = xb + (long)kc * CK * HW;
     // software-pipelined k-steps (step = tap x channel pair): the LDS gathers + blend of step s+1 are
     // issued before the MFMAs of step s
@@ -272,15 +282,18 @@ static int launch_dcn_patch(DcnArgs& a, int tile, hipStream_t st) {
   // tile = 10*MT + t:  MT = 2 = 64 output channels per work-group (128 measured slower); 128-pixel 2-D tiles,
   // t in {0,1,2} = 4x32 / 8x16 / 16x8 (rows x cols)
   const int mt = tile / 10, tw = tile % 10;
+  // 16-byte window DMA where image rows and planes are 16-byte aligned (SGTA_DCN_VEC=0: always the 4-byte form)
+  static const bool allow_vec = !(getenv("SGTA_DCN_VEC") && atoi(getenv("SGTA_DCN_VEC")) == 0);
+  const bool vec = allow_vec && a.W % 4 == 0 && a.x_bs % 4 == 0 && ((uintptr_t)a.x & 15) == 0;
   if (mt == 2 && a.Cout_pad % 64 == 0) {
-    if (tw == 0) return go(dcn_patch_kernel<2, 1, 32, R, CK, ACT>, 64, 1, 32);
-    if (tw == 1) return go(dcn_patch_kernel<2, 1, 16, R, CK, ACT>, 64, 1, 16);
-    if (tw == 2) return go(dcn_patch_kernel<2, 1, 8, R, CK, ACT>, 64, 1, 8);
+    if (tw == 0) return vec ? go(dcn_patch_kernel<2, 1, 32, R, CK, ACT, true>, 64, 1, 32) : go(dcn_patch_kernel<2, 1, 32, R, CK, ACT, false>, 64, 1, 32);
+    if (tw == 1) return vec ? go(dcn_patch_kernel<2, 1, 16, R, CK, ACT, true>, 64, 1, 16) : go(dcn_patch_kernel<2, 1, 16, R, CK, ACT, false>, 64, 1, 16);
+    if (tw == 2) return vec ? go(dcn_patch_kernel<2, 1, 8, R, CK, ACT, true>, 64, 1, 8) : go(dcn_patch_kernel<2, 1, 8, R, CK, ACT, false>, 64, 1, 8);
   }
   if (mt == 4 && a.Cout_pad % 128 == 0) {            // 128 output channels per work-group: every gathered value feeds 4 MFMAs
-    if (tw == 0) return go(dcn_patch_kernel<4, 1, 32, R, CK, ACT>, 128, 1, 32);
-    if (tw == 1) return go(dcn_patch_kernel<4, 1, 16, R, CK, ACT>, 128, 1, 16);
-    if (tw == 2) return go(dcn_patch_kernel<4, 1, 8, R, CK, ACT>, 128, 1, 8);
+    if (tw == 0) return vec ? go(dcn_patch_kernel<4, 1, 32, R, CK, ACT, true>, 128, 1, 32) : go(dcn_patch_kernel<4, 1, 32, R, CK, ACT, false>, 128, 1, 32);
+    if (tw == 1) return vec ? go(dcn_patch_kernel<4, 1, 16, R, CK, ACT, true>, 128, 1, 16) : go(dcn_patch_kernel<4, 1, 16, R, CK, ACT, false>, 128, 1, 16);
+    if (tw == 2) return vec ? go(dcn_patch_kernel<4, 1, 8, R, CK, ACT, true>, 128, 1, 8) : go(dcn_patch_kernel<4, 1, 8, R, CK, ACT, false>, 128, 1, 8);
   }
   return SGTA_EBADARG;
 }
