@@ -266,16 +266,16 @@ extern "C" int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* w
   const int mt = tile / 10, tw = tile % 10;
   // 16-byte window DMA where rows and planes are 16-byte aligned (SGTA_S2_VEC=0 keeps the 4-byte de-interleaved form)
   static const bool allow_vec = !(getenv("SGTA_S2_VEC") && atoi(getenv("SGTA_S2_VEC")) == 0);
-  const bool vec = allow_vec && W % 4 == 0 && x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0 && tw == 0;
+  const bool vec = allow_vec && W % 4 == 0 && x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0;
   if (mt == 2 && Cout_pad % 64 == 0) {
     if (tw == 0) return vec ? go(conv3x3_s2_kernel<2, 32, true>, 64, 32) : go(conv3x3_s2_kernel<2, 32, false>, 64, 32);
-    if (tw == 1) return go(conv3x3_s2_kernel<2, 16, false>, 64, 16);
-    if (tw == 2) return go(conv3x3_s2_kernel<2, 8, false>, 64, 8);
+    if (tw == 1) return vec ? go(conv3x3_s2_kernel<2, 16, true>, 64, 16) : go(conv3x3_s2_kernel<2, 16, false>, 64, 16);
+    if (tw == 2) return vec ? go(conv3x3_s2_kernel<2, 8, true>, 64, 8) : go(conv3x3_s2_kernel<2, 8, false>, 64, 8);
   }
   if (mt == 1) {
     if (tw == 0) return vec ? go(conv3x3_s2_kernel<1, 32, true>, 32, 32) : go(conv3x3_s2_kernel<1, 32, false>, 32, 32);
-    if (tw == 1) return go(conv3x3_s2_kernel<1, 16, false>, 32, 16);
-    if (tw == 2) return go(conv3x3_s2_kernel<1, 8, false>, 32, 8);
+    if (tw == 1) return vec ? go(conv3x3_s2_kernel<1, 16, true>, 32, 16) : go(conv3x3_s2_kernel<1, 16, false>, 32, 16);
+    if (tw == 2) return vec ? go(conv3x3_s2_kernel<1, 8, true>, 32, 8) : go(conv3x3_s2_kernel<1, 8, false>, 32, 8);
   }
   return SGTA_EBADARG;
 }
