@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the SGTAPose inference hot path on MI355X (contract: see the task's bench rules).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height H] [--width W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height H] [--width W] [--dtype f32|bf16]
+
+``--gpus N`` with N > 1 launches itself: the parent (which never touches the GPU) starts N fresh rank
+processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), rank 0
+prints the one JSON line, and the parent exits non-zero if any rank fails.  Under ``python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` the ranks are the launcher's.
 
 One "step" = one pass of the WHOLE hot path over one batch of synthetic frame pairs per GPU:
 two-frame DLA-34 backbone, temporal cross-attention (all six levels), DCN neck, heads with fused
-sigmoid, device decode (peaks + gathers), and -- for N > 1 -- the RCCL all-gather of the [B,7,3]
-keypoints.  Inputs are resident in HBM before the timed region.  Workload at N=1: BASELINE.json
-configs[1] (batch 32, 2-frame 480x640, fp32); the same per-GPU batch for N>1 (weak scaling, the
-batch shards over ranks with no data-path collective except the keypoint all-gather).
+sigmoid, device decode (peaks + gathers + the [B,7,3] key-point tensor), and -- for N > 1 -- the RCCL
+all-gather of those key-points.  Inputs are resident in HBM before the timed region.  Workload at N=1:
+BASELINE.json configs[1] (batch 32, 2-frame 480x640, fp32); the same per-GPU batch for N>1 (weak scaling:
+the batch shards over ranks with no data-path collective except the key-point all-gather).
 
-After the timed region the same process (a) re-runs a few steps with HIP events around every C-ABI
-launch (on the launch stream) to get the per-kernel durations the ``roofline`` object is computed
-from, and (b) on rank 0 at N=1 times the CPU oracle (our restatement of the reference path; the
-reference's Python cannot travel to the GPU box) on a bounded sample for ``cpu_baseline``.
+After the timed region rank 0 (a) re-runs a few LOCAL steps (no collective) with HIP events around every
+C-ABI launch, on the launch stream, for the per-kernel durations behind ``roofline``; (b) at N=1 times the
+CPU oracle (our restatement of the reference path; the reference's Python cannot travel to the GPU box) on
+a bounded sample for ``cpu_baseline`` and checks the benched batch itself against it (``parity``).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,18 +32,60 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 
-import torch  # noqa: E402
+import torch  # noqa: E402  (importing torch does not initialise the GPU)
 
 ARGS = ("x", "pre_img", "pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")
-PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD
+PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD at 2.4 GHz
+PEAK_TFLOPS_BF16_MFMA = 2500.0      # dense bf16 MFMA (the guide's ~2.5 PF; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0               # HBM3E spec
+PMC_TABLE = os.path.join(REPO, "profiles", "r02_pmc_step_by_kernel.csv")
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_model(dev, seed=0, arch="dlapawdl3new_34"):
+# ---------------------------------------------------------------------------------------------------------
+# self-launch: one fresh process per GPU, started BEFORE anything in this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, need_gpus=True):
+    if need_gpus and torch.cuda.device_count() < n:          # counting devices does not initialise the GPU
+        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (n, torch.cuda.device_count()))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0 inherits stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(enumerate(procs))
+        while pending:
+            for item in list(pending):
+                r, p = item
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(item)
+                if code != 0:
+                    log("rank %d exited with code %d" % (r, code))
+                    rc = rc or code
+                    for _, q in pending:       # a dead rank would leave the others hanging in a collective
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------
+def build_model(dev, seed=0, arch="dlapawdl3new_34", peaked=False, frames=2):
     from util import golden_state_dict
     from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
     if arch == "dlapawd3_34":                     # three-frame variant
@@ -45,7 +93,7 @@ def build_model(dev, seed=0, arch="dlapawdl3new_34"):
         sd = golden_state_dict(seed, keys="model_keys_three.json")
         model = create_model(arch, heads, default_head_conv(heads), default_opt())
     else:
-        sd = golden_state_dict(seed)
+        sd = golden_state_dict(seed, peaked=peaked)
         model = create_model(arch, DEFAULT_HEADS, default_head_conv(), default_opt())
     model.load_state_dict(sd, strict=True)
     return model.to(dev).eval(), sd
@@ -76,74 +124,169 @@ def instrumented_pass(run_step, steps):
     return agg
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/r01_pmc_step_by_kernel.csv:
-    separate ``rocprofv3 --pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` runs of this same command, see profiles/README.md),
-    with the guide's gfx950 correction (FETCH_SIZE tallies the 128-byte requests of 16-B/lane streams -- the window
-    and weight LDS-DMA of this kernel -- at 64 bytes: doubled).  bench.py cannot collect PMCs itself; None if the
-    table or the kernel is missing."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_step_by_kernel.csv")
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes (separate ``rocprofv3 --pmc FETCH_SIZE`` /
+    ``--pmc WRITE_SIZE`` runs of THIS command, condensed by tools/summarize_step_pmc.py, which also records the
+    workload and the commit the passes were made at).  bench.py cannot collect counters itself; the table is used only
+    when its workload matches this run's, otherwise traffic is null.  gfx950 correction per the guide: FETCH_SIZE
+    tallies the 128-byte requests of 16-B/lane streams at 64 bytes -> doubled."""
     try:
         import csv
-        for r in csv.DictReader(open(path)):
+        meta = json.load(open(PMC_TABLE + ".meta.json"))
+        if any(meta.get(k) != v for k, v in workload.items()):
+            return None, "PMC table %s is for %s, this run is %s" % (os.path.basename(PMC_TABLE), meta, workload), None
+        for r in csv.DictReader(open(PMC_TABLE)):
             if r["kernel"] == kernel:
                 n = int(r["launches"])
                 byts = (2.0 * float(r["FETCH_SIZE_MB_raw"]) + float(r["WRITE_SIZE_MB_raw"])) * 1e6 / n
-                return round(byts), ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) / %d launches of one step, "
-                                     "profiles/r01_pmc_step_by_kernel.csv (separate --pmc passes; not collected live)" % n)
+                return round(byts), ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) / %d launches of one step, %s "
+                                     "(separate --pmc passes of this command; not collected live)"
+                                     % (n, os.path.relpath(PMC_TABLE, REPO))), meta.get("commit")
     except (OSError, KeyError, ValueError):
         pass
-    return None, "no PMC table for this kernel under profiles/"
+    return None, "no PMC table for this kernel / workload under profiles/", None
 
 
-def cpu_baseline(sd, H, W, det=None, dev=None, budget_s=20.0):
-    """The CPU oracle (kind 'port') on B=1 frame pairs of the same workload, all host cores; the same sample then
-    goes through the HIP path and the heat-map / key-point deviation is reported beside the timing ('parity')."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def cpu_baseline(sd, inp, hip_out, hip_dets, budget_b8_s=60.0):
+    """The CPU oracle (kind 'port') timed on frame pairs OF THE BENCHED BATCH, all host threads: B=1 (median of 5 after
+    2 warm-ups, five different samples) and B=8 (median of up to 5 after 1-2 warm-ups, bounded by ``budget_b8_s``).
+    The B=1 outputs double as the parity reference for the same samples of the HIP batch (``parity``)."""
     import numpy as np
     import oracle
-    from sgtapose_amd.synthetic import make_inputs
+    B = inp["x"].shape[0]
+    H, W = inp["x"].shape[2:]
     cores = torch.get_num_threads()
-    inp = make_inputs(1, H, W, seed=999)
-    a = [inp[k] for k in ARGS]
-    ref_out, ref_dets = oracle.process_reference(sd, *a)   # warm-up (and the parity reference)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        oracle.process_reference(sd, *a)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 16:
-            break
-    res = {"value": round(n / el, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-           "sample": "%d x (B=1, %dx%d) frame pairs through oracle.process_reference (forward + sigmoid + "
-                     "decode), %d torch threads, %.1f s" % (n, H, W, cores, el)}
-    if det is not None:
-        out, dets = det.process_device(*[t.to(dev) for t in a])
-        kp_hip = det.keypoints(dets)[0].cpu().numpy().astype(np.float64)           # [7, 3] = x, y, score
-        kp_ref = np.concatenate([ref_dets["cts_wreg"][0].reshape(7, 2), ref_dets["scores"][0].reshape(7, 1)], 1)
-        found = kp_ref[:, 2] >= 0
-        res["parity"] = {
-            "hm_max_abs": float((out["hm"].cpu() - ref_out["hm"]).abs().max()),
-            "reg_max_abs": float((out["reg"].cpu() - ref_out["reg"]).abs().max()),
-            "tracking_max_abs": float((out["tracking"].cpu() - ref_out["tracking"]).abs().max()),
-            "keypoints_found_ref": int(found.sum()),
-            "keypoints_found_same": bool(np.array_equal(found, kp_hip[:, 2] >= 0)),
-            "keypoint_l2_max_px": float(np.sqrt(((kp_hip[found, :2] - kp_ref[found, :2]) ** 2).sum(1)).max()) if found.any() else 0.0,
-            "bar": "1e-3 abs (north_star); same seeded sample through the CPU oracle and the HIP path"}
-        # random-init logits are flat (no peaks): key-point parity of the decode on peaked maps fed to both decoders
-        from sgtapose_amd.decode import dream_generic_decode
-        from sgtapose_amd.synthetic import peaked_heatmaps
-        hm, _ = peaked_heatmaps(4, H // 4, W // 4, seed=7)
-        reg, trk = ref_out["reg"].repeat(4, 1, 1, 1), ref_out["tracking"].repeat(4, 1, 1, 1)
-        got = dream_generic_decode({"hm": hm.to(dev), "reg": reg.to(dev), "tracking": trk.to(dev)}, K=7)
-        ref = oracle.dream_decode({"hm": hm, "reg": reg, "tracking": trk})
-        d = (got["cts_wreg"].cpu().double() - ref["cts_wreg"].double()).reshape(-1, 2)
-        res["parity"]["decode_peaked_maps"] = {
-            "keypoints": int((ref["scores"] > 0).sum()),
-            "integer_peaks_identical": bool(torch.equal(got["xs"].cpu(), ref["xs"]) and torch.equal(got["ys"].cpu(), ref["ys"])),
-            "keypoint_l2_max_px": float(d.pow(2).sum(1).sqrt().max())}
-    return res
+
+    def run(idx):
+        a = [inp[k][idx] for k in ARGS]
+        t0 = time.perf_counter()
+        o = oracle.process_reference(sd, *a)
+        return time.perf_counter() - t0, o
+
+    picks = sorted({0, B // 4, B // 2, (3 * B) // 4, B - 1})
+    while len(picks) < 5:
+        picks.append(picks[-1])
+    for _ in range(2):
+        run(slice(0, 1))
+    t1, refs = [], {}
+    for i in picks:
+        dt, o = run(slice(i, i + 1))
+        t1.append(dt)
+        refs[i] = o
+    res = {"value": round(1.0 / _median(t1), 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+           "cpu": cpu_model(),
+           "sample": "B=1: median of %d runs after 2 warm-ups, samples %s of the benched batch (%dx%d) through "
+                     "oracle.process_reference (forward + sigmoid + decode), %d torch threads"
+                     % (len(t1), picks, H, W, cores)}
+    if B >= 8:
+        t8, t_start, warm = [], time.perf_counter(), 0
+        while len(t8) < 5 and (time.perf_counter() - t_start < budget_b8_s or len(t8) < 2):
+            dt, _ = run(slice(0, 8))
+            if warm < (2 if dt < 6.0 else 1):
+                warm += 1
+                continue
+            t8.append(dt)
+        res["b8"] = {"value": round(8.0 / _median(t8), 4), "unit": "frame-pairs/s", "runs": len(t8), "warmups": warm,
+                     "sample": "B=8: samples 0..7 of the benched batch in one oracle call, median of %d runs" % len(t8)}
+    # ---- parity of the benched batch: the same samples through the HIP path (they ran at the full batch size) ----
+    err = {k: 0.0 for k in ("hm", "reg", "tracking")}
+    found_ref = found_same = int_same = 0
+    l2 = 0.0
+    hip_kp = hip_dets["kp"]
+    for i, (o, d) in refs.items():
+        for k in err:
+            err[k] = max(err[k], float((hip_out[k][i:i + 1].cpu() - o[k]).abs().max()))
+        kp_ref = np.concatenate([d["cts_wreg"][0].reshape(7, 2), d["scores"][0].reshape(7, 1)], 1)
+        kp_hip = hip_kp[i].cpu().numpy().astype(np.float64)
+        f = kp_ref[:, 2] >= 0
+        found_ref += int(f.sum())
+        found_same += int(np.array_equal(f, kp_hip[:, 2] >= 0))
+        int_same += int(np.array_equal(hip_dets["xs"][i].cpu().numpy(), d["xs"][0]) and
+                        np.array_equal(hip_dets["ys"][i].cpu().numpy(), d["ys"][0]))
+        if f.any():
+            l2 = max(l2, float(np.sqrt(((kp_hip[f, :2] - kp_ref[f, :2]) ** 2).sum(1)).max()))
+    res["parity"] = {"samples_of_benched_batch": sorted(refs), "hm_max_abs": err["hm"], "reg_max_abs": err["reg"],
+                     "tracking_max_abs": err["tracking"], "keypoints_found_ref": found_ref,
+                     "found_masks_identical": found_same == len(refs),
+                     "integer_peaks_identical": int_same == len(refs), "keypoint_l2_max_px": l2,
+                     "bar": "1e-3 abs (north_star); HIP ran these samples inside the full benched batch"}
+    return res, refs
 
 
+def peaked_parity(dev, inp, picks, dtype):
+    """Key-point parity with the second weight set (peaked heat-maps): the benched inputs through
+    a model whose 'hm' head emits isolated peaks, HIP at the full batch size vs the oracle on ``picks``; then both
+    decode dictionaries through post-process -> final_kps."""
+    import numpy as np
+    import oracle
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import PEAKED_HM_BIAS, PEAKED_HM_GAIN
+    model, sd = build_model(dev, peaked=True)
+    if dtype == "bf16":
+        model.engine_dtype = "bf16"
+    det = BatchedDetector(model)
+    out, dets = det.process_device(*[inp[k].to(dev) for k in ARGS])
+    kp = det.keypoints(dets).cpu().numpy().astype(np.float64)
+    found = same_int = n = 0
+    l2 = hm = 0.0
+    for i in picks:
+        o, d = oracle.process_reference(sd, *[inp[k][i:i + 1] for k in ARGS])
+        f = d["scores"][0] >= 0
+        found += int(f.sum())
+        n += 7
+        hm = max(hm, float((out["hm"][i:i + 1].cpu() - o["hm"]).abs().max()))
+        same_int += int(np.array_equal(dets["xs"][i].cpu().numpy(), d["xs"][0]) and
+                        np.array_equal(dets["ys"][i].cpu().numpy(), d["ys"][0]))
+        if f.any():
+            l2 = max(l2, float(np.sqrt(((kp[i][f, :2] - d["cts_wreg"][0].reshape(7, 2)[f]) ** 2).sum(1)).max()))
+    return {"weights": "peaked set (hm.2.weight x %g, bias %g)" % (PEAKED_HM_GAIN, PEAKED_HM_BIAS),
+            "samples_of_benched_batch": list(picks), "keypoints_found_ref": found, "keypoints_total": n,
+            "integer_peaks_identical": same_int == len(picks), "keypoint_l2_max_px": l2, "hm_max_abs": hm}
+
+
+def dry_run(args):
+    """The multi-rank control flow of main() without the GPU: gloo group, one all-gather of fake [B,7,3] key-points per
+    step, barrier + max-over-ranks timing, rank 0 prints the JSON line (marked dry_run)."""
+    import torch.distributed as dist
+    from sgtapose_amd.distributed import gather_keypoints
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    kp = torch.full((B, 7, 3), float(rank))
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        allkp = gather_keypoints(kp, world * B)
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = tuple(allkp.shape) == (world * B, 7, 3) and all(float(allkp[r * B, 0, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": dist.get_world_size(), "gather_ok": ok,
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+# ---------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +297,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--arch", default="dlapawdl3new_34", choices=["dlapawdl3new_34", "dlapawd3_34"],
                     help="dlapawd3_34 = the reference's three-frame variant (frame triples/s; not the headline metric)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE configs[1] (the headline); bf16 = configs[2]'s data path (bf16 feature maps / "
+                         "weights on bf16 MFMA, fp32 accumulate / softmax / LayerNorm / decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--early-levels", default=None,
@@ -162,15 +308,20 @@ def main():
     ap.add_argument("--skip-dead-levels", action="store_true",
                     help="do not compute temporal levels 0/1 (they never reach the heads); NOT the default")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / key-point all-gather plumbing only, on the CPU with gloo (no GPU work, "
+                         "no timing claim): what tests/test_distributed.py runs in the build container")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, need_gpus=not args.dry_run))     # parent: never touches the GPU
+    if args.dry_run:
+        return dry_run(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -184,11 +335,16 @@ def main():
     B, H, W = args.batch, args.height, args.width
     model, sd = build_model(dev, arch=args.arch)
     three = args.arch == "dlapawd3_34"
+    if args.dtype == "bf16":
+        if three:
+            raise SystemExit("--dtype bf16 is built for dlapawdl3new_34")
+        model.engine_dtype = "bf16"
     if three:
         args.no_cpu_baseline = True                 # the CPU baseline / parity leg is the two-frame oracle's
-    model.engine().compute_dead_levels = not args.skip_dead_levels
+    eng = model.engine()
+    eng.compute_dead_levels = not args.skip_dead_levels
     if args.early_levels is not None:
-        model.engine().early_levels = tuple(int(v) for v in args.early_levels.split(",") if v != "")
+        eng.early_levels = tuple(int(v) for v in args.early_levels.split(",") if v != "")
     det = BatchedDetector(model)
     if three:
         from sgtapose_amd.synthetic import THREE_ARGS, make_inputs_three
@@ -200,10 +356,14 @@ def main():
     from sgtapose_amd.distributed import gather_keypoints
     state = {}
 
+    def local_step():
+        out, dets = det.process_device(*dev_in, static=True)
+        state["out"], state["dets"], state["kp"] = out, dets, det.keypoints(dets)
+
     def run_step():
-        _, dets = det.process_device(*dev_in, static=True)
+        local_step()
         # the path's only exchange step: all-gather of the [B,7,3] keypoints (RCCL when world > 1)
-        state["kp_all"] = gather_keypoints(det.keypoints(dets), world * B)
+        state["kp_all"] = gather_keypoints(state["kp"], world * B)
 
     def barrier():
         if dist is not None:
@@ -218,34 +378,39 @@ def main():
         run_step()
     barrier()
     el = time.perf_counter() - t0
+    ranks_seen = 1
     if dist is not None:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+        ranks_seen = dist.get_world_size()
+        assert tuple(state["kp_all"].shape) == (world * B, 7, 3)
 
-    cfg_name = {(32, 480, 640): "configs[1]", (16, 736, 1280): "configs[3] (720p padded to a multiple of 32)"}.get(
-        (B, H, W), "custom")
+    cfg_name = {(32, 480, 640, "f32"): "configs[1]", (32, 480, 640, "bf16"): "configs[2] per-GPU shard (32 pairs, bf16)",
+                (16, 736, 1280, "f32"): "configs[3] (720p padded to a multiple of 32)"}.get((B, H, W, args.dtype), "custom")
     if three:
         cfg_name = "three-frame variant dlapawd3_34 (seq_len 3: the reference's widest; towards configs[4])"
     result = {
         "metric": "%s/sec @%dx%d" % ("frame-triples" if three else "frame-pairs", args.height, args.width),
         "value": round(world * B * args.steps / el, 3),
         "unit": "frame-triples/s" if three else "frame-pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * el / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg_name + ": batch=%d 2-frame %dx%d synthetic pairs per GPU, dlapawdl3new_34 "
-                               "random-init (seeded), full backbone + temporal attention (6 levels) + DCN neck + "
-                               "heads + sigmoid + peak decode%s" % (B, H, W, " + RCCL all-gather of keypoints" if world > 1 else ""),
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": cfg_name + ": batch=%d 2-frame %dx%d synthetic pairs per GPU, %s random-init (seeded), "
+                               "full backbone + temporal attention (6 levels) + DCN neck + heads + sigmoid + peak "
+                               "decode%s" % (B, H, W, args.arch, " + RCCL all-gather of keypoints" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": world * B, "net_input": [H, W],
                    "parallelism": "dp%d (batch shards, weights replicated)" % world,
                    "dead_levels_computed": not args.skip_dead_levels,
-                   "workspace_GB": round(model.engine().workspace_bytes() / 2 ** 30, 2)},
+                   "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2)},
     }
 
+    # everything below is rank-0-only and collective-free (the other ranks wait in the final barrier)
     if rank == 0 and not args.no_roofline:
-        agg = instrumented_pass(run_step, 2)
+        peak = PEAK_TFLOPS_BF16_MFMA if args.dtype == "bf16" else PEAK_TFLOPS_F32_MFMA
+        agg = instrumented_pass(local_step, 2)
         tot = sum(a["ms"] for a in agg.values())
         rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
         if args.breakdown:
@@ -255,33 +420,46 @@ def main():
                 gb = a["bytes"] / a["ms"] / 1e6 if a["bytes"] else 0
                 log("%-44s %8.3f %5.1f%% %9.1f %9.0f  x%d" % (k, a["ms"], 100 * a["ms"] / tot, tf, gb, a["launches"]))
             log("sum of kernel time %.2f ms/step (event-bracketed), timed region %.2f ms/step" % (tot, 1e3 * el / args.steps))
-        top, ta = rows[0]
-        ach = ta["flops"] / ta["ms"] / 1e9                     # TFLOP/s, algorithmic (un-padded) flops
+        top, ta = next((k, a) for k, a in rows if a["flops"] or a["bytes"])
+        eff = ta["flops"] / ta["ms"] / 1e9                     # TFLOP/s, algorithmic (direct-form, un-padded) flops
         exe = ta["exec_flops"] / ta["ms"] / 1e9                # TFLOP/s actually issued to the matrix pipe
-        result["roofline"] = {"kernel": top, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F32_MFMA,
-                              "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F32_MFMA, 4), "traffic": None,
-                              "executed": round(exe, 2), "executed_frac": round(exe / PEAK_TFLOPS_F32_MFMA, 4),
-                              "note": "achieved = algorithmic (direct-conv, un-padded) FLOPs / measured kernel time; "
-                                      "the Winograd kernels issue only 16/36 (F(2x2,3x3)) or 36/144 (F(4x4,3x3)) of them to "
-                                      "the matrix pipe, so achieved may exceed the f32 MFMA peak while executed_frac is "
-                                      "the matrix-pipe utilisation",
-                              "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
-                              "share_of_step": round(ta["ms"] / tot, 3)}
-        result["roofline"]["traffic"], result["roofline"]["traffic_note"] = pmc_traffic(top)
+        gbs = ta["bytes"] / ta["ms"] / 1e6                     # GB/s of algorithmic (compulsory) bytes
+        mfma_frac, hbm_frac = exe / peak, gbs / PEAK_HBM_GBS
+        bound = "hbm" if hbm_frac > mfma_frac else "mfma"
+        wl = {"batch": B, "height": H, "width": W, "arch": args.arch, "dtype": args.dtype}
+        traffic, tnote, tcommit = pmc_traffic(top, wl)
+        result["roofline"] = {
+            "kernel": top, "bound": bound,
+            "achieved": round(gbs if bound == "hbm" else exe, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak,
+            "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "frac": round(hbm_frac if bound == "hbm" else mfma_frac, 4),
+            "traffic": traffic, "traffic_note": tnote, "traffic_commit": tcommit,
+            "effective_tflops": round(eff, 2), "executed_tflops": round(exe, 2), "mfma_frac": round(mfma_frac, 4),
+            "alg_GBs": round(gbs, 1), "hbm_frac": round(hbm_frac, 4),
+            "note": "frac = work actually issued / peak of the binding unit (never > 1): executed matrix FLOPs (a Winograd "
+                    "kernel issues 16/36 or 36/144 of the direct-form multiplies) / MFMA peak, or algorithmic bytes / HBM "
+                    "peak; effective_tflops = direct-form algorithmic FLOPs / time",
+            "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
+            "share_of_step": round(ta["ms"] / tot, 3)}
         extra = []
         for k, a in rows:
             if a["flops"]:
                 extra.append({"kernel": k, "ms_per_step": round(a["ms"], 3),
                               "tflops": round(a["flops"] / a["ms"] / 1e9, 2),
                               "executed_tflops": round(a["exec_flops"] / a["ms"] / 1e9, 2),
-                              "mfma_frac": round(a["exec_flops"] / a["ms"] / 1e9 / PEAK_TFLOPS_F32_MFMA, 4),
+                              "mfma_frac": round(a["exec_flops"] / a["ms"] / 1e9 / peak, 4),
                               "alg_GBs": round(a["bytes"] / a["ms"] / 1e6, 1),
                               "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
         result["kernels"] = extra
         result["other_kernels_ms"] = {k: round(a["ms"], 3) for k, a in rows if not a["flops"]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(sd, H, W, det, dev)
+        local_step()
+        torch.cuda.synchronize()
+        cb, refs = cpu_baseline(sd, inp, state["out"], state["dets"])
+        picks = sorted(refs)[::2][:3]
+        cb["parity"]["peaked_weights"] = peaked_parity(dev, inp, picks, args.dtype)
+        result["cpu_baseline"] = cb
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -240,6 +240,16 @@ int sgta_peaks_decode_full(const float* hm, const float* reg, const float* track
                            float* regs, float* trks, int* npeaks, long long* cts, float* cts_wreg,
                            float* regs_rel, int B, int K, int H, int W, int three_pass, sgta_stream_t stream);
 
+/* sgta_peaks_decode_full plus kp f32 [B,K,3] = (x + reg_x, y + reg_y, score) per key-point (x + 0.5, y + 0.5 without
+ * a 'reg' head, decode.py:304-306): the tensor SURVEY.md section 8e all-gathers across ranks, written by the decode
+ * kernel itself so that the step needs no element-wise glue.  regs / trks, when given, are zero-filled for a missing
+ * head.  kp may be NULL. */
+int sgta_peaks_decode_kp(const float* hm, const float* reg, const float* tracking, const double* gauss_w13,
+                         float* ws_tmp, float* ws_filt, float* scores, long long* xs, long long* ys,
+                         float* regs, float* trks, int* npeaks, long long* cts, float* cts_wreg,
+                         float* regs_rel, float* kp, int B, int K, int H, int W, int three_pass,
+                         sgta_stream_t stream);
+
 /* SoftArgmaxPavlo.forward (sgtapose/spatial_softmax.py:24-95): out_xy f32 [B,K,2] = (E[col], E[row]). */
 int sgta_softargmax(const float* hm, float* out_xy, int B, int K, int H, int W, float beta,
                     float size_mult, sgta_stream_t stream);

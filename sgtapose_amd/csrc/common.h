@@ -19,6 +19,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Host-side caches of per-device facts (resident work-groups, function attributes) are indexed by the CURRENT device:
+// one process may drive several GPUs (tests, replicas), and hipFuncSetAttribute is per-device state.
+#define SGTA_MAX_DEVICES 64
+static inline int sgta_device_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev % SGTA_MAX_DEVICES;
+}
+
 // XCD-aware 1-D block remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
 // Logical ids are laid out so that ``inner`` consecutive logical ids (e.g. the cout tiles of one
 // pixel tile) run back-to-back on ONE XCD and hit its L2.  Bijective for any (n_outer, inner);

@@ -434,8 +434,8 @@ static int launch_wino(WinoArgs& a, int tile, long a_ws_floats, hipStream_t st) 
         break;
       }
     // persistent: as many work-groups as the device holds at once (2 per CU), never more than items
-    static int resident_by_tile[4] = {0, 0, 0, 0};          // per <ACT, RES> instance and tile shape
-    int& resident = resident_by_tile[tile];
+    static int resident_by_tile[SGTA_MAX_DEVICES][4] = {};    // per <ACT, RES> instance, device and tile shape
+    int& resident = resident_by_tile[sgta_device_slot()][tile];
     if (!resident) {
       int dev = 0, cus = 0, per_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess ||

@@ -315,8 +315,8 @@ static int launch_wino4(Wino4Args& a, int tile, hipStream_t st) {
     a.blk_r = cdiv(cdiv(a.H, 4), TR);
     a.blk_c = cdiv(cdiv(a.W, 4), TC);
     a.n_pt = a.B * a.blk_r * a.blk_c;
-    static int resident_by_tile[4] = {0, 0, 0, 0};          // per <ACT, RES> instance and tile shape
-    int& resident = resident_by_tile[tile];
+    static int resident_by_tile[SGTA_MAX_DEVICES][4] = {};    // per <ACT, RES> instance, device and tile shape
+    int& resident = resident_by_tile[sgta_device_slot()][tile];
     if (!resident) {
       int dev = 0, cus = 0, per_cu = 0;
       if (hipGetDevice(&dev) != hipSuccess ||

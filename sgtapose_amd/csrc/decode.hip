@@ -67,11 +67,37 @@ __device__ __forceinline__ void cand_insert(Cand& c0, Cand& c1, const Cand& n) {
   else if (cand_before(n, c1)) { c1 = n; }
 }
 
-extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const float* tracking,
-                                      const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
-                                      long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
-                                      long long* cts, float* cts_wreg, float* regs_rel, int B, int K, int H, int W,
-                                      int three_pass, hipStream_t st);
+extern "C" int sgta_peaks_decode_kp(const float* hm, const float* reg, const float* tracking,
+                                    const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
+                                    long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
+                                    long long* cts, float* cts_wreg, float* regs_rel, float* kp, int B, int K, int H,
+                                    int W, int three_pass, hipStream_t st);
+
+// shared tail of both selection kernels: the decode dictionary's entries of one map (decode.py:296-312) and the
+// [x + reg_x, y + reg_y, score] key-point row that is all-gathered across ranks
+__device__ __forceinline__ void emit_map(int map, int b, int HW, int W, long long xi, long long yi, float sc, int n,
+                                         const float* reg, const float* trk, float* scores, long long* xs,
+                                         long long* ys, float* regs, float* trks, int* npeaks, long long* cts,
+                                         float* cts_wreg, float* regs_rel, float* kp) {
+  scores[map] = sc; xs[map] = xi; ys[map] = yi;
+  if (npeaks) npeaks[map] = n;
+  const long ind = yi * W + xi;
+  float rg[2] = {0.0f, 0.0f};
+  for (int c = 0; c < 2; ++c) {
+    if (reg) rg[c] = reg[((long)b * 2 + c) * HW + ind];
+    if (regs) regs[map * 2 + c] = rg[c];
+    if (trks) trks[map * 2 + c] = trk ? trk[((long)b * 2 + c) * HW + ind] : 0.0f;
+  }
+  if (cts) { cts[map * 2] = xi; cts[map * 2 + 1] = yi; }
+  const float fx = (float)xi, fy = (float)yi;
+  // without a 'reg' head the reference adds 0.5 (decode.py:304-306)
+  const float wx = __fadd_rn(fx, reg ? rg[0] : 0.5f), wy = __fadd_rn(fy, reg ? rg[1] : 0.5f);
+  if (cts_wreg && reg) {
+    cts_wreg[map * 2] = wx; cts_wreg[map * 2 + 1] = wy;
+    if (regs_rel) { regs_rel[map * 2] = __fsub_rn(wx, fx); regs_rel[map * 2 + 1] = __fsub_rn(wy, fy); }
+  }
+  if (kp) { kp[map * 3] = wx; kp[map * 3 + 1] = wy; kp[map * 3 + 2] = sc; }
+}
 
 // one work-group per (b, class) map
 __global__ __launch_bounds__(256) void peaks_select_kernel(
@@ -79,7 +105,7 @@ __global__ __launch_bounds__(256) void peaks_select_kernel(
     const float* __restrict__ trk, float* __restrict__ scores, long long* __restrict__ xs,
     long long* __restrict__ ys, float* __restrict__ regs, float* __restrict__ trks,
     int* __restrict__ npeaks, long long* __restrict__ cts, float* __restrict__ cts_wreg,
-    float* __restrict__ regs_rel, int K, int H, int W) {
+    float* __restrict__ regs_rel, float* __restrict__ kp, int K, int H, int W) {
   const int map = blockIdx.x, b = map / K;
   const int HW = H * W;
   const float* ori = hm + (long)map * HW;
@@ -135,21 +161,7 @@ __global__ __launch_bounds__(256) void peaks_select_kernel(
       yi = (long long)best.cy;
       sc = ori[yi * W + xi];
     }
-    scores[map] = sc; xs[map] = xi; ys[map] = yi;
-    if (npeaks) npeaks[map] = n;
-    const long ind = yi * W + xi;
-    float rg[2] = {0.0f, 0.0f};
-    for (int c = 0; c < 2; ++c) {
-      if (reg) { rg[c] = reg[((long)b * 2 + c) * HW + ind]; regs[map * 2 + c] = rg[c]; }
-      if (trk) trks[map * 2 + c] = trk[((long)b * 2 + c) * HW + ind];
-    }
-    if (cts) { cts[map * 2] = xi; cts[map * 2 + 1] = yi; }
-    if (cts_wreg && reg) {
-      const float fx = (float)xi, fy = (float)yi;
-      const float wx = __fadd_rn(fx, rg[0]), wy = __fadd_rn(fy, rg[1]);
-      cts_wreg[map * 2] = wx; cts_wreg[map * 2 + 1] = wy;
-      if (regs_rel) { regs_rel[map * 2] = __fsub_rn(wx, fx); regs_rel[map * 2 + 1] = __fsub_rn(wy, fy); }
-    }
+    emit_map(map, b, HW, W, xi, yi, sc, n, reg, trk, scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, kp);
   }
 }
 
@@ -285,7 +297,8 @@ __global__ __launch_bounds__(64) void peaks_merge_kernel(
     const TileCands* __restrict__ tc, int ntiles, const float* __restrict__ hm, const float* __restrict__ reg,
     const float* __restrict__ trk, float* __restrict__ scores, long long* __restrict__ xs, long long* __restrict__ ys,
     float* __restrict__ regs, float* __restrict__ trks, int* __restrict__ npeaks, long long* __restrict__ cts,
-    float* __restrict__ cts_wreg, float* __restrict__ regs_rel, int nmaps, int K, int H, int W) {
+    float* __restrict__ cts_wreg, float* __restrict__ regs_rel, float* __restrict__ kp, int nmaps, int K, int H,
+    int W) {
   const int map = blockIdx.x * 64 + threadIdx.x;
   if (map >= nmaps) return;
   const int b = map / K, HW = H * W;
@@ -306,21 +319,7 @@ __global__ __launch_bounds__(64) void peaks_merge_kernel(
     yi = (long long)best.cy;
     sc = ori[yi * W + xi];
   }
-  scores[map] = sc; xs[map] = xi; ys[map] = yi;
-  if (npeaks) npeaks[map] = n;
-  const long ind = yi * W + xi;
-  float rg[2] = {0.0f, 0.0f};
-  for (int c = 0; c < 2; ++c) {
-    if (reg) { rg[c] = reg[((long)b * 2 + c) * HW + ind]; regs[map * 2 + c] = rg[c]; }
-    if (trk) trks[map * 2 + c] = trk[((long)b * 2 + c) * HW + ind];
-  }
-  if (cts) { cts[map * 2] = xi; cts[map * 2 + 1] = yi; }
-  if (cts_wreg && reg) {
-    const float fx = (float)xi, fy = (float)yi;
-    const float wx = __fadd_rn(fx, rg[0]), wy = __fadd_rn(fy, rg[1]);
-    cts_wreg[map * 2] = wx; cts_wreg[map * 2 + 1] = wy;
-    if (regs_rel) { regs_rel[map * 2] = __fsub_rn(wx, fx); regs_rel[map * 2 + 1] = __fsub_rn(wy, fy); }
-  }
+  emit_map(map, b, HW, W, xi, yi, sc, n, reg, trk, scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, kp);
 }
 
 static bool gauss_peaks_fits(int W, size_t* bytes) {
@@ -336,8 +335,8 @@ extern "C" int sgta_peaks_decode(const float* hm, const float* reg, const float*
                                  const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
                                  long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
                                  int B, int K, int H, int W, hipStream_t st) {
-  return sgta_peaks_decode_full(hm, reg, tracking, gauss_w13, ws_tmp, ws_filt, scores, xs, ys, regs, trks, npeaks,
-                                nullptr, nullptr, nullptr, B, K, H, W, 0, st);
+  return sgta_peaks_decode_kp(hm, reg, tracking, gauss_w13, ws_tmp, ws_filt, scores, xs, ys, regs, trks, npeaks,
+                              nullptr, nullptr, nullptr, nullptr, B, K, H, W, 0, st);
 }
 
 extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const float* tracking,
@@ -345,6 +344,15 @@ extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const f
                                       long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
                                       long long* cts, float* cts_wreg, float* regs_rel, int B, int K, int H, int W,
                                       int three_pass, hipStream_t st) {
+  return sgta_peaks_decode_kp(hm, reg, tracking, gauss_w13, ws_tmp, ws_filt, scores, xs, ys, regs, trks, npeaks, cts,
+                              cts_wreg, regs_rel, nullptr, B, K, H, W, three_pass, st);
+}
+
+extern "C" int sgta_peaks_decode_kp(const float* hm, const float* reg, const float* tracking,
+                                    const double* gauss_w13, float* ws_tmp, float* ws_filt, float* scores,
+                                    long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
+                                    long long* cts, float* cts_wreg, float* regs_rel, float* kp, int B, int K, int H,
+                                    int W, int three_pass, hipStream_t st) {
   if (!hm || !gauss_w13 || !ws_tmp || !ws_filt || !scores || !xs || !ys) return SGTA_EBADARG;
   if (B <= 0 || K <= 0 || H <= 0 || W <= 0 || (reg && !regs) || (tracking && !trks)) return SGTA_EBADARG;
   if ((cts_wreg || regs_rel) && !reg) return SGTA_EBADARG;
@@ -355,7 +363,8 @@ extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const f
   const bool fused = !three_pass && gauss_peaks_fits(W, &lds) && ((uintptr_t)ws_tmp & 7) == 0 &&
                      (size_t)ntiles * sizeof(TileCands) <= (size_t)H * W * sizeof(float);
   if (fused) {
-    static bool attr_set = false;
+    static bool attr_set_by_dev[SGTA_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_by_dev[sgta_device_slot()];
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_peaks_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
@@ -365,7 +374,7 @@ extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const f
     TileCands* tc = reinterpret_cast<TileCands*>(ws_tmp);
     hipLaunchKernelGGL(gauss_peaks_kernel, dim3(ntiles, B * K), dim3(256), lds, st, hm, ws_filt, gauss_w13, tc, H, W);
     hipLaunchKernelGGL(peaks_merge_kernel, dim3((B * K + 63) / 64), dim3(64), 0, st, (const TileCands*)tc, ntiles, hm,
-                       reg, tracking, scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, B * K, K, H, W);
+                       reg, tracking, scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, kp, B * K, K, H, W);
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   }
@@ -373,7 +382,7 @@ extern "C" int sgta_peaks_decode_full(const float* hm, const float* reg, const f
   hipLaunchKernelGGL(gauss1d_kernel<0>, dim3(grid), dim3(256), 0, st, hm, ws_tmp, gauss_w13, H, W, total);
   hipLaunchKernelGGL(gauss1d_kernel<1>, dim3(grid), dim3(256), 0, st, (const float*)ws_tmp, ws_filt, gauss_w13, H, W, total);
   hipLaunchKernelGGL(peaks_select_kernel, dim3(B * K), dim3(256), 0, st, hm, (const float*)ws_filt, reg, tracking,
-                     scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, K, H, W);
+                     scores, xs, ys, regs, trks, npeaks, cts, cts_wreg, regs_rel, kp, K, H, W);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

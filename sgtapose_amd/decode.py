@@ -6,7 +6,7 @@ import torch
 from . import ops
 
 
-def dream_generic_decode(output, K=7, opt=None, ws=None):
+def dream_generic_decode(output, K=7, opt=None, ws=None, out=None):
     if "hm" not in output:
         return {}
     if opt is not None and getattr(opt, "zero_tracking", False):
@@ -15,7 +15,7 @@ def dream_generic_decode(output, K=7, opt=None, ws=None):
     B, cat, H, W = heat.shape
     if cat != K:
         raise ValueError("K must equal the number of heat-map classes")
-    d = ops.peaks_decode(heat, output.get("reg"), output.get("tracking"), ws)
+    d = ops.peaks_decode(heat, output.get("reg"), output.get("tracking"), ws, out=out)
     xs0, ys0 = d["xs"], d["ys"]
     ret = {"scores": d["scores"], "clses": _clses(B, cat, heat.device), "xs": xs0, "ys": ys0, "cts": d["cts"]}
     if "reg" in output:
@@ -32,6 +32,7 @@ def dream_generic_decode(output, K=7, opt=None, ws=None):
     if "tracking" in output:
         ret["tracking"] = d["trks"]
     ret["npeaks"] = d["npeaks"]
+    ret["kp"] = d["kp"]                # [B,K,3] = (x + reg_x, y + reg_y, score): BatchedDetector.keypoints / all-gather
     return ret
 
 

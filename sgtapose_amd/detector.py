@@ -23,7 +23,8 @@ class BatchedDetector:
         out = eng.forward(*inputs, hm_act=ops.ACT_SIGMOID, static=static)
         hm = out["hm"]
         ws = (eng.buf("dec_tmp", tuple(hm.shape)), eng.buf("dec_filt", tuple(hm.shape)))
-        dets = dream_generic_decode(out, K=self.K, opt=self.opt, ws=ws)
+        bufs = ops.decode_buffers(hm.shape[0], self.K, hm.device, "reg" in out, alloc=eng.buf) if static else None
+        dets = dream_generic_decode(out, K=self.K, opt=self.opt, ws=ws, out=bufs)
         return out, dets
 
     def process(self, images, pre_images=None, pre_hms=None, repro_hms=None, pre_inds=None,
@@ -35,7 +36,7 @@ class BatchedDetector:
         torch.cuda.synchronize()
         forward_time = time.time()
         hms = output["hm"][0]
-        dets = {k: v.detach().cpu().numpy() for k, v in dets.items()}
+        dets = {k: v.detach().cpu().numpy() for k, v in dets.items() if k != "kp"}   # 'kp' is this build's extra
         return (output, dets, forward_time, hms) if return_time else (output, dets)
 
     # ---- the steps either side of the network, on the device ------------------
@@ -75,4 +76,4 @@ class BatchedDetector:
     @staticmethod
     def keypoints(dets):
         """[B,K,3] float32 (x + reg_x, y + reg_y, score) -- the tensor that is all-gathered across ranks."""
-        return torch.cat([dets["cts_wreg"].squeeze(-1), dets["scores"].unsqueeze(-1)], dim=2).float()
+        return dets["kp"]                  # written by the decode kernel (sgta_peaks_decode_kp): no glue kernels

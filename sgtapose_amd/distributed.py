@@ -31,8 +31,8 @@ def shard_inputs(inputs, rank, world):
 
 def gather_keypoints(kp_local, global_batch=None, group=None):
     """All-gather [B_local, K, 3] keypoints into [B_global, K, 3] in rank order (ragged shards allowed)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return kp_local
+    if not (dist.is_available() and dist.is_initialized()):
+        return kp_local                    # no process group: single-GPU run (a world of 1 still runs the collective)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     gb = global_batch if global_batch is not None else kp_local.shape[0] * world
     sizes = [shard_bounds(gb, r, world) for r in range(world)]

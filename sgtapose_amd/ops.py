@@ -303,7 +303,9 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
         _lib.call("sgta_conv3x3s2_f32", x.ptr, x.bs, pc.wt_s2.data_ptr(), pc.bias.data_ptr(), out.ptr, out.bs,
                   x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, code, _stream(), meta=meta)
         return out
-    if (USE_WINOGRAD and USE_WINO4 and pc.u_wino4 is not None and tile == 0 and x.W % 4 == 0 and x.bs % 4 == 0
+    # epilogues the two Winograd entry points instantiate: (act, res_mode) in _WINO_EPILOGUES; others fall through
+    wino_ok = (act, res_mode if res is not None else 0) in _WINO_EPILOGUES
+    if (wino_ok and USE_WINOGRAD and USE_WINO4 and pc.u_wino4 is not None and tile == 0 and x.W % 4 == 0 and x.bs % 4 == 0
             and out.bs % 4 == 0 and x.ptr % 16 == 0 and out.ptr % 16 == 0
             and (res is None or (rbs % 4 == 0 and rp % 16 == 0))):
         code, util = pc.wino4_tile(x.H, x.W)
@@ -317,7 +319,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
                       out.ptr, out.bs, x.B, pc.Cin, x.H, x.W, pc.Cout, pc.Cout_pad, act,
                       res_mode if res is not None else 0, code, _stream(), meta=meta)
             return out
-    if USE_WINOGRAD and pc.u_wino is not None and tile == 0:
+    if wino_ok and USE_WINOGRAD and pc.u_wino is not None and tile == 0:
         code = pc.wino_tile(x.H, x.W) if WINO_TILE_OVERRIDE is None else WINO_TILE_OVERRIDE
         meta = None
         if _lib.PROFILE is not None:
@@ -348,6 +350,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
+_WINO_EPILOGUES = {(ACT_NONE, 0), (ACT_RELU, 0), (ACT_RELU, 1), (ACT_RELU, 2), (ACT_SIGMOID, 0)}
 _SPLITK_WS = {}
 
 
@@ -614,32 +617,40 @@ def gauss_taps(device):
     return _GAUSS[key]
 
 
-def peaks_decode(hm, reg=None, tracking=None, ws=None, three_pass=False):
-    """hm [B,K,H,W] post-sigmoid.  Returns dict(scores, xs, ys, regs, trks, npeaks, cts[, cts_wreg, regs_rel]) of
-    device tensors (the last two only with ``reg``).  ``three_pass`` forces the un-fused kernels (cross-check)."""
+def decode_buffers(B, K, dev, with_reg=True, alloc=None):
+    """The output tensors of ``peaks_decode`` (the engine passes its workspace allocator so that a step allocates
+    nothing)."""
+    alloc = alloc or (lambda name, shape, dtype: torch.empty(shape, dtype=dtype, device=dev))
+    out = dict(scores=alloc("dec_scores", (B, K), torch.float32), xs=alloc("dec_xs", (B, K), torch.int64),
+               ys=alloc("dec_ys", (B, K), torch.int64), regs=alloc("dec_regs", (B, K, 2), torch.float32),
+               trks=alloc("dec_trks", (B, K, 2), torch.float32), npeaks=alloc("dec_npeaks", (B, K), torch.int32),
+               cts=alloc("dec_cts", (B, K, 2), torch.int64), kp=alloc("dec_kp", (B, K, 3), torch.float32))
+    if with_reg:
+        out["cts_wreg"] = alloc("dec_cts_wreg", (B, K, 2), torch.float32)
+        out["regs_rel"] = alloc("dec_regs_rel", (B, K, 2), torch.float32)
+    return out
+
+
+def peaks_decode(hm, reg=None, tracking=None, ws=None, three_pass=False, out=None):
+    """hm [B,K,H,W] post-sigmoid.  Returns dict(scores, xs, ys, regs, trks, npeaks, cts, kp[, cts_wreg, regs_rel]) of
+    device tensors (the last two only with ``reg``; ``kp`` [B,K,3] = x + reg_x, y + reg_y, score).  ``three_pass``
+    forces the un-fused kernels (cross-check); ``out`` = pre-allocated ``decode_buffers``."""
     _req(hm)
     B, K, H, W = hm.shape
     dev = hm.device
     hm = hm.contiguous()
     if ws is None:
         ws = (torch.empty_like(hm), torch.empty_like(hm))
-    out = dict(scores=torch.empty(B, K, dtype=torch.float32, device=dev),
-               xs=torch.empty(B, K, dtype=torch.int64, device=dev),
-               ys=torch.empty(B, K, dtype=torch.int64, device=dev),
-               regs=torch.zeros(B, K, 2, dtype=torch.float32, device=dev),
-               trks=torch.zeros(B, K, 2, dtype=torch.float32, device=dev),
-               npeaks=torch.empty(B, K, dtype=torch.int32, device=dev),
-               cts=torch.empty(B, K, 2, dtype=torch.int64, device=dev))
-    if reg is not None:
-        out["cts_wreg"] = torch.empty(B, K, 2, dtype=torch.float32, device=dev)
-        out["regs_rel"] = torch.empty(B, K, 2, dtype=torch.float32, device=dev)
-    _lib.call("sgta_peaks_decode_full", hm.data_ptr(), None if reg is None else _req(reg.contiguous()).data_ptr(),
+    if out is None:
+        out = decode_buffers(B, K, dev, reg is not None)
+    _lib.call("sgta_peaks_decode_kp", hm.data_ptr(), None if reg is None else _req(reg.contiguous()).data_ptr(),
               None if tracking is None else _req(tracking.contiguous()).data_ptr(),
               gauss_taps(dev).data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), out["scores"].data_ptr(),
               out["xs"].data_ptr(), out["ys"].data_ptr(), out["regs"].data_ptr(), out["trks"].data_ptr(),
               out["npeaks"].data_ptr(), out["cts"].data_ptr(),
               out["cts_wreg"].data_ptr() if reg is not None else None,
-              out["regs_rel"].data_ptr() if reg is not None else None, B, K, H, W, int(three_pass), _stream())
+              out["regs_rel"].data_ptr() if reg is not None else None, out["kp"].data_ptr(), B, K, H, W,
+              int(three_pass), _stream())
     return out
 
 

@@ -26,8 +26,15 @@ def _uniform(shape, lo, hi, g):
     return torch.rand(shape, generator=g) * (hi - lo) + lo
 
 
-def fill_state_dict_(sd, seed=0):
-    """In-place, deterministic re-initialisation of a state_dict (keys follow the reference)."""
+PEAKED_HM_GAIN = 30.0      # second weight set: the 'hm' output conv scaled and its bias lowered
+PEAKED_HM_BIAS = -8.0      # so that the random-init heat-maps carry isolated peaks the decode can find
+
+
+def fill_state_dict_(sd, seed=0, peaked=False):
+    """In-place, deterministic re-initialisation of a state_dict (keys follow the reference).  ``peaked`` = the
+    second weight set of SURVEY.md section 8d: identical except hm.2.weight * PEAKED_HM_GAIN and hm.2.bias =
+    PEAKED_HM_BIAS (random-init logits are flat around the -4.6 prior bias = the decode's 0.01 threshold, so the
+    default set yields no key-points; this one does, for network -> decode -> post-process parity)."""
     done = set()
     for name in sorted(sd.keys()):
         t = sd[name]
@@ -57,7 +64,7 @@ def fill_state_dict_(sd, seed=0):
                 if leaf == "weight":
                     t.copy_(_uniform(t.shape, 0.7, 1.3, g))
                 elif canon.startswith("hm.2."):
-                    t.fill_(-4.6)                # prior_bias (base_model.py:151-152)
+                    t.fill_(PEAKED_HM_BIAS if peaked else -4.6)      # prior_bias (base_model.py:151-152)
                 else:
                     t.copy_(_uniform(t.shape, -0.1, 0.1, g))
             elif ".up_" in canon:                # depthwise transposed conv: near-bilinear, perturbed
@@ -70,6 +77,8 @@ def fill_state_dict_(sd, seed=0):
                 fan_in = t[0].numel()
                 b = (3.0 / fan_in) ** 0.5 * 1.2
                 t.copy_(_uniform(t.shape, -b, b, g))
+                if peaked and canon == "hm.2.weight":
+                    t.mul_(PEAKED_HM_GAIN)
     return sd
 
 

@@ -44,7 +44,7 @@ def save(name, **arrs):
     print("wrote %-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
 
 
-def fullnet(model, tag, B, H, W, seed, first_frame=False, extra=False):
+def fullnet(model, tag, B, H, W, seed, first_frame=False, extra=False, probe=False):
     ref = load_reference()
     inp = make_inputs(B, H, W, seed=seed, first_frame=first_frame)
     opt = type("O", (), {"zero_tracking": False})()
@@ -59,6 +59,14 @@ def fullnet(model, tag, B, H, W, seed, first_frame=False, extra=False):
             dets.append(ref.decode.dream_generic_decode(ob, K=7, opt=opt))
     arrs = dict(meta=np.array([B, H, W, seed, int(first_frame)]), hm_logits=hm_logits,
                 reg=out["reg"], tracking=out["tracking"])
+    if probe:
+        # large batches: the heads at 4096 seeded probe pixels per sample + per-map statistics instead of full maps
+        g = torch.Generator().manual_seed(seed)
+        pix = torch.randint(0, (H // 4) * (W // 4), (4096,), generator=g)
+        flat = lambda t: t.reshape(B, t.shape[1], -1)             # noqa: E731
+        arrs = dict(meta=arrs["meta"], probe_pix=pix, hm_probe=flat(hm_logits)[:, :, pix],
+                    reg_probe=flat(out["reg"])[:, :, pix], tracking_probe=flat(out["tracking"])[:, :, pix],
+                    hm_map_max=flat(hm_logits).max(2)[0], hm_map_mean=flat(hm_logits).double().mean(2))
     for k in dets[0]:
         arrs["det_" + k] = torch.cat([d[k] for d in dets], 0)
     if extra:
@@ -220,9 +228,21 @@ def three_frames():
                  **{k: v for k, v in out.items()})
 
 
+def peaked():
+    """Second weight set (peaked heat-maps): reference network -> sigmoid ->
+    dream_generic_decode; the decode dictionaries hold real key-points (scores > 0)."""
+    model, _ = build_reference_model()
+    fill_state_dict_(model.state_dict(), seed=0, peaked=True)
+    fullnet(model, "peaked_128x160", 4, 128, 160, 11)
+    fullnet(model, "peaked_480x640", 4, 480, 640, 317, probe=True)
+
+
 def main():
     if "--three-only" in sys.argv:
         three_frames()
+        return
+    if "--peaked-only" in sys.argv:
+        peaked()
         return
     if "--prepost-only" in sys.argv:
         prepost_ops()
@@ -244,6 +264,7 @@ def main():
     fullnet(model, "96x160", 1, 96, 160, 319)
     fullnet(model, "480", 1, 480, 480, 320)
     fullnet(model, "480x640", 1, 480, 640, 321)
+    peaked()
 
 
 if __name__ == "__main__":

@@ -61,3 +61,21 @@ def test_shard_bounds_cover_batch_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(8, 2, 2)
+
+
+def test_bench_self_launches_ranks_and_gathers(tmp_path):
+    """``python bench.py --gpus 2`` (no torchrun): the parent spawns the ranks, rank 0 prints ONE JSON line, exit code 0.
+    --dry-run keeps it on the CPU (gloo) -- the launcher, rendezvous and all-gather flow are those of the GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run", "--batch", "3",
+                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["ranks_seen"] == 2 and rec["n_gpus"] == 2 and rec["gather_ok"] is True

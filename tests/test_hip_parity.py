@@ -35,6 +35,15 @@ def model():
     return m.to(DEV).eval()
 
 
+@pytest.fixture(scope="module")
+def model_peaked():
+    """Second weight set: the 'hm' head emits isolated peaks, so the decode finds key-points."""
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
+    m.load_state_dict(golden_state_dict(0, peaked=True), strict=True)
+    return m.to(DEV).eval()
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cin,cout,ks,stride,tile", [
     (3, 16, 7, 1, 0), (1, 16, 7, 1, 1), (16, 16, 3, 1, 0), (16, 32, 3, 2, 0), (32, 64, 1, 1, 2),
@@ -513,7 +522,7 @@ def test_decode_matches_reference_bit_exact(ops):
             assert got.shape == ref.shape and got.dtype == ref.dtype, k
             assert np.array_equal(got, ref), k
     sa = ops.soft_argmax(hm.to(DEV))
-    assert torch.allclose(sa.cpu(), t(g["softargmax"]), atol=1e-3)
+    assert torch.allclose(sa.cpu(), t(g["softargmax"]), atol=1e-4)      # same bar as the oracle's own check
 
 
 def test_gaussian_filter_bit_exact_vs_scipy(ops):
@@ -807,3 +816,142 @@ def test_three_frame_model_matches_reference(tag):
     for k in out:
         err = float((out[k].cpu() - t(g[k])).abs().max())
         assert out[k].shape == g[k].shape and err < 1e-3, (k, err)
+
+
+# ---- end to end with real key-points: network -> sigmoid -> decode -> post-process -> final_kps ---------------------
+@pytest.mark.parametrize("tag", ["peaked_128x160", "peaked_480x640"])
+def test_peaked_weights_keypoints_end_to_end(model_peaked, tag):
+    """The REFERENCE network with the peaked weight set produced these decode dictionaries (fixture): integer peaks
+    bit-exact, sub-pixel centres / offsets / tracking within 1e-3, then both dictionaries through post-process ->
+    final_kps (the key-points the PnP solver consumes)."""
+    from oracle import prepost as op
+    from sgtapose_amd import prepost
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    g = golden("fullnet_%s.npz" % tag)
+    B, H, W, seed, first = [int(v) for v in g["meta"]]
+    inp = make_inputs(B, H, W, seed=seed, first_frame=bool(first))
+    det = BatchedDetector(model_peaked)
+    out, dets = det.process_device(*[inp[k].to(DEV) for k in ARGS])
+    found = g["det_scores"] > 0
+    assert int(found.sum()) >= 2
+    if "hm_logits" in g.files:
+        assert float((out["hm"].cpu() - torch.sigmoid(t(g["hm_logits"]))).abs().max()) < 1e-3
+    else:
+        pix = t(g["probe_pix"])
+        got = out["hm"].cpu().reshape(B, 7, -1)[:, :, pix]
+        assert float((got - torch.sigmoid(t(g["hm_probe"]))).abs().max()) < 1e-3
+    for k in ("xs", "ys", "cts"):
+        assert np.array_equal(dets[k].cpu().numpy(), g["det_" + k]), k
+    assert np.array_equal(dets["scores"].cpu().numpy() > 0, found)
+    for k in ("scores", "cts_wreg", "regs", "tracking"):
+        assert np.allclose(dets[k].cpu().numpy(), g["det_" + k], atol=1e-3, rtol=0), k
+    kp = det.keypoints(dets).cpu().numpy()
+    assert np.allclose(kp[..., :2], g["det_cts_wreg"][..., 0], atol=1e-3) and np.allclose(kp[..., 2], g["det_scores"], atol=1e-3)
+    # post-process + final key-points: HIP chain on the HIP dets vs the oracle chain on the REFERENCE's dets
+    c, s_ = np.array([W / 2.0, H / 2.0], np.float32), float(max(W, H))
+    t_inv = np.stack([op.get_affine_transform(c, s_, 0, (W // 4, H // 4), inv=1)] * B)
+    pp = prepost.post_process_device(dets, t_inv.astype(np.float32), 0.01)
+    ref_dets = {k[4:]: g[k] for k in g.files if k.startswith("det_")}
+    ref_items = op.dream_generic_post_process(ref_dets, t_inv, 0.01)
+    fk = pp["final_kps"].cpu().numpy()
+    for b in range(B):
+        ref_fk = op.get_final_kps(ref_items[b], 7)
+        miss = ref_fk[:, 0] < -3000
+        assert np.array_equal(fk[b][miss], ref_fk[miss])
+        assert np.allclose(fk[b][~miss], ref_fk[~miss], atol=4e-3, rtol=0)      # 1e-3 map pixels x 4 (output stride)
+    assert int((fk[..., 0] > -3000).sum()) == int((g["det_scores"] >= 0.01).sum())
+
+
+@pytest.mark.parametrize("B,H,W,picks", [(32, 480, 640, (0, 15, 31)), (16, 736, 1280, (0, 15))])
+def test_benched_configurations_match_oracle(model, model_peaked, B, H, W, picks):
+    """BASELINE configs[1] (B=32, 480x640) and configs[3] (B=16, 736x1280) AT THEIR BENCHED BATCH SIZE -- the
+    dispatcher takes other kernels there (128-channel DCN work-groups, stacked images, persistent grids) than at the
+    B<=2 of the fixtures.  First / middle / last samples of the HIP batch against the oracle run on those samples
+    alone (frame pairs are independent), with both weight sets; key-points of the peaked set compared too."""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    inp = make_inputs(B, H, W, seed=317)
+    dev_in = [inp[k].to(DEV) for k in ARGS]
+    for m, peaked in ((model, False), (model_peaked, True)):
+        det = BatchedDetector(m)
+        out, dets = det.process_device(*dev_in, static=True)
+        sd = golden_state_dict(0, peaked=peaked)
+        for i in picks:
+            ref_out, ref_dets = oracle.process_reference(sd, *[inp[k][i:i + 1] for k in ARGS])
+            for k in ("hm", "reg", "tracking"):
+                err = float((out[k][i:i + 1].cpu() - ref_out[k]).abs().max())
+                assert err < 1e-3, (peaked, i, k, err)
+            assert np.array_equal(dets["xs"][i].cpu().numpy(), ref_dets["xs"][0]), (peaked, i)
+            assert np.array_equal(dets["ys"][i].cpu().numpy(), ref_dets["ys"][0]), (peaked, i)
+            assert np.allclose(dets["cts_wreg"][i].cpu().numpy(), ref_dets["cts_wreg"][0], atol=1e-3, rtol=0)
+            assert np.allclose(dets["scores"][i].cpu().numpy(), ref_dets["scores"][0], atol=1e-3, rtol=0)
+        del det
+    m.engine().bufs.clear()
+    model_peaked.engine().bufs.clear()
+    model.engine().bufs.clear()
+    torch.cuda.empty_cache()
+
+
+def test_dcnv2_hip_matches_torchvision_deform_conv2d(ops):
+    """Third-party pin of the HIP DCN where torchvision is installed (not in this image)."""
+    tvo = pytest.importorskip("torchvision.ops")
+    from sgtapose_amd.ops import PackedConv, View
+    g = torch.Generator().manual_seed(12)
+    for (B, Ci, Co, H, W, s) in ((2, 16, 64, 17, 23, 1.5), (1, 64, 64, 30, 40, 4.0)):
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.2
+        b = torch.randn(Co, generator=g)
+        om = torch.randn(B, 27, H, W, generator=g) * s
+        o1, o2, m = torch.chunk(om, 3, dim=1)
+        ref = tvo.deform_conv2d(x, torch.cat([o1, o2], 1), w, b, padding=1, mask=torch.sigmoid(m))
+        pc = PackedConv(w.to(DEV), b.to(DEV), None, tap_major=True)
+        out = torch.empty(B, Co, H, W, device=DEV)
+        ops.dcn_v2(View(x.to(DEV)), View(om.to(DEV)), pc, View(out))
+        assert torch.allclose(out.cpu(), ref, atol=2e-4), float((out.cpu() - ref).abs().max())
+
+
+def test_rccl_all_gather_of_keypoints_world_of_one():
+    """The path's only collective over RCCL (backend "nccl") on device tensors: a world of ONE still runs
+    all_gather_into_tensor through RCCL (more ranks need more GPUs; the gloo tests cover world 2)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from sgtapose_amd.distributed import gather_keypoints
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        kp = torch.randn(5, 7, 3, device=DEV)
+        got = gather_keypoints(kp, 5)
+        torch.cuda.synchronize()
+        assert got.data_ptr() != kp.data_ptr() and torch.equal(got, kp)
+        assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_cli_emits_one_json_line_with_roofline_and_parity():
+    """bench.py end to end on a small workload: one JSON line, roofline.frac <= 1, parity of the benched batch with
+    real key-points from the peaked weight set."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--height", "128", "--width", "160"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["dtype"] == "f32"
+    assert 0 < r["roofline"]["frac"] <= 1.0 and r["roofline"]["bound"] in ("mfma", "hbm")
+    par = r["cpu_baseline"]["parity"]
+    assert par["hm_max_abs"] < 1e-3 and par["reg_max_abs"] < 1e-3 and par["tracking_max_abs"] < 1e-3
+    assert par["peaked_weights"]["integer_peaks_identical"] and par["peaked_weights"]["keypoint_l2_max_px"] < 1e-3
+    assert r["cpu_baseline"]["cores"] >= 1 and "b8" in r["cpu_baseline"]

@@ -115,6 +115,51 @@ def test_fullnet_matches_reference(tag):
         assert np.allclose(v, ref, atol=1e-5), k
 
 
+@pytest.mark.parametrize("tag", ["peaked_128x160", "peaked_480x640"])
+def test_fullnet_peaked_weights_match_reference(tag):
+    """Second weight set (peaked heat-maps): network -> sigmoid -> decode of the REFERENCE
+    (fixture) against the oracle -- real key-points (scores > 0), so the chain is pinned end to end."""
+    g = golden("fullnet_%s.npz" % tag)
+    B, H, W, seed, first = [int(v) for v in g["meta"]]
+    inp = make_inputs(B, H, W, seed=seed, first_frame=bool(first))
+    sd = golden_state_dict(0, peaked=True)
+    out, dets = oracle.process_reference(sd, *[inp[k] for k in ARGS])
+    assert int((g["det_scores"] > 0).sum()) >= 2
+    # (the fixture was produced with ONE torch thread; conv summation order differs with more, x the hm gain of 30)
+    if "hm_logits" in g.files:
+        assert torch.allclose(out["hm"], torch.sigmoid(t(g["hm_logits"])), atol=2e-5)
+        assert torch.allclose(out["reg"], t(g["reg"]), atol=1e-5)
+    else:                                                    # probe pixels of the large fixture
+        pix = t(g["probe_pix"])
+        flat = lambda v: v.reshape(B, v.shape[1], -1)[:, :, pix]       # noqa: E731
+        assert torch.allclose(flat(out["hm"]), torch.sigmoid(t(g["hm_probe"])), atol=2e-5)
+        assert torch.allclose(flat(out["reg"]), t(g["reg_probe"]), atol=1e-5)
+        assert torch.allclose(flat(out["tracking"]), t(g["tracking_probe"]), atol=1e-5)
+    for k in ("xs", "ys", "cts", "clses"):
+        assert np.array_equal(dets[k], g["det_" + k]), k
+    for k in ("scores", "cts_wreg", "regs", "tracking"):
+        assert np.allclose(dets[k], g["det_" + k], atol=2e-5), k
+
+
+def test_dcnv2_oracle_matches_torchvision_deform_conv2d():
+    """Third-party pin for SURVEY.md section 8a9: torchvision.ops.deform_conv2d implements the same modulated
+    deformable convolution as lbin/DCNv2 (Appendix B).  torchvision is not in this image -> skipped here; the test
+    runs wherever it is installed."""
+    tvo = pytest.importorskip("torchvision.ops")
+    g = torch.Generator().manual_seed(12)
+    for (B, Ci, Co, H, W, s) in ((2, 8, 6, 7, 9, 1.5), (1, 16, 12, 11, 5, 6.0), (1, 4, 4, 15, 20, 0.3)):
+        x = torch.randn(B, Ci, H, W, generator=g)
+        w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.2
+        b = torch.randn(Co, generator=g)
+        omw = torch.randn(27, Ci, 3, 3, generator=g) * (s / (Ci * 9) ** 0.5)
+        omb = torch.randn(27, generator=g) * 0.3
+        om = torch.nn.functional.conv2d(x, omw, omb, padding=1)
+        o1, o2, m = torch.chunk(om, 3, dim=1)
+        ref = tvo.deform_conv2d(x, torch.cat([o1, o2], 1), w, b, padding=1, mask=torch.sigmoid(m))
+        got = oracle.dcn_v2_forward(x, w, b, omw, omb)
+        assert torch.allclose(got, ref, atol=1e-4), float((got - ref).abs().max())
+
+
 def test_dcnv2_torch_oracle_matches_plain_c_witness():
     """oracle/dcnv2.py (torch) against oracle/dcnv2_ref.c (scalar C): two independent restatements of the
     published lbin/DCNv2 algorithm (parity unpinned by the reference, see oracle/__init__.py)."""

@@ -21,13 +21,13 @@ def model_keys(name="model_keys.json"):
 _SD_CACHE = {}
 
 
-def golden_state_dict(seed=0, keys="model_keys.json"):
+def golden_state_dict(seed=0, keys="model_keys.json", peaked=False):
     """The reference model's state_dict entries (560 for dlapawdl3new_34), rebuilt from (seed, name, shape) alone."""
     from sgtapose_amd.synthetic import fill_state_dict_
-    if (seed, keys) not in _SD_CACHE:
+    if (seed, keys, peaked) not in _SD_CACHE:
         sd = {}
         for k, shape in model_keys(keys):
             dt = torch.long if k.endswith("num_batches_tracked") else torch.float32
             sd[k] = torch.zeros(shape, dtype=dt)
-        _SD_CACHE[(seed, keys)] = fill_state_dict_(sd, seed)
-    return _SD_CACHE[(seed, keys)]
+        _SD_CACHE[(seed, keys, peaked)] = fill_state_dict_(sd, seed, peaked=peaked)
+    return _SD_CACHE[(seed, keys, peaked)]

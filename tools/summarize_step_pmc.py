@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel-family PMC table over ONE full bench step (the last of the run).
 
-    python tools/summarize_step_pmc.py <sq_dir> <fetch_dir> <write_dir> [out.csv]
+    python tools/summarize_step_pmc.py <sq_dir> <fetch_dir> <write_dir> [out.csv] [key=value ...]
+(key=value pairs -- batch= height= width= arch= dtype= commit= -- are written to <out.csv>.meta.json: bench.py takes
+``roofline.traffic`` from the table only when they match its own workload, and records the commit.)
 Each directory = one `rocprofv3 --pmc ... --output-format csv -d <dir> -- python3 bench.py --steps 1 --warmup 1
 --no-cpu-baseline --no-roofline` pass (SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... / FETCH_SIZE / WRITE_SIZE)."""
 import collections
@@ -30,7 +32,9 @@ def last_step(by):
     """Dispatches of the last step: everything from the second-to-last stem launch on.  The passes are separate
     runs and the side streams interleave differently in each, so they are summed per kernel family, never paired."""
     keys = list(by.keys())
-    start = [i for i, k in enumerate(keys) if k[1].startswith("stem_c16")][-2]
+    stems = [i for i, k in enumerate(keys) if k[1].startswith("stem_")]
+    per_step = 2 if len(stems) >= 2 and any("c16" in keys[i][1] for i in stems) else 1   # f32: one stem launch per frame
+    start = stems[-per_step]
     return [(k[1], by[k]) for k in keys[start:]]
 
 
@@ -60,6 +64,12 @@ def main():
     print(txt)
     if len(sys.argv) > 4:
         open(sys.argv[4], "w").write(txt + "\n")
+        import json
+        meta = {}
+        for kv in sys.argv[5:]:
+            k, v = kv.split("=", 1)
+            meta[k] = int(v) if v.isdigit() else v
+        json.dump(meta, open(sys.argv[4] + ".meta.json", "w"))
 
 
 if __name__ == "__main__":
