@@ -1,0 +1,270 @@
+// bf16 data path (BASELINE configs[2]): convolution (+ folded BN bias, residual, activation) on bf16 NHWC feature
+// maps with bf16 weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Replaces the same reference code as
+// sgta_conv2d_f32 (dla.py:41-69, :157-231, :302-312; DCN offset/mask conv; heads base_model.py:121-135).
+//
+// Layout: channels-last, so the MFMA B operand of a pixel (8 consecutive k = 8 consecutive input channels of one tap)
+// is ONE 16-byte read, and the A operand (8 consecutive k of one output channel) is one 16-byte read of the packed
+// weights.  D[cout, pixel]: the pixel sits on the lane, 4 consecutive output channels in 4 accumulator registers ->
+// 8-byte bf16 NHWC stores (or fp32 NHWC / fp32 NCHW for the tensors that leave the bf16 domain).
+//
+// Tiling: the batch is ONE tall image of N*(H+1) rows (one zero row under every image, so a tile may span images and
+// every tap is a constant LDS offset); a 512-thread work-group owns TR x TW = 256 / 512 output positions x TC = 32 / 64 /
+// 128 output channels, each of its 8 waves 32 / 64 positions x all TC channels.  Per chunk of KC input channels the
+// (S(TR-1)+KS) x (S(TW-1)+KS) input window and the [tap][TC][KC] weight image arrive by 16-byte buffer LDS-DMA
+// (out-of-image window slots carry an out-of-range offset: the bounds check writes zeros), double buffered, one barrier
+// per chunk.  LDS rows are KC*2 bytes; 16-byte pieces are XOR-swizzled with the row index (on the DMA source side for
+// the window, at pack time for the weights) so the ds_read_b128 fragment reads are conflict-free.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct CbArgs {
+  const void* x;    long x_bytes;  int ldx;      // bf16 NHWC input (pointer at the view's first channel), bytes reachable
+  const void* wt;   long wt_bytes;               // packed [n_ct][nchunks][taps][TC][KC] bf16, swizzled
+  const float* bias;                             // [n_ct * TC]
+  const __bf16* res; int ldr;                    // residual, bf16 NHWC at the output resolution (or null)
+  void* y;          int ldy;                     // bf16 NHWC / fp32 NHWC (ldy = channels per pixel) or fp32 NCHW
+  int N, H, W, Ho, Wo, Cout, nchunks, n_ct, n_rt, n_xt, log_tw, act, out_mode, nsig;
+};
+
+template <int KS, int S, int KC, int NPF>
+struct CbGeom {
+  static constexpr int TP = 256 * NPF;                                // output positions per work-group
+  static constexpr int TAPS = KS * KS, KSTEPS = KC / 16, P = KC / 8, ROWB = KC * 2;
+  static constexpr int LOG_R = KC == 16 ? 3 : (KC == 32 ? 2 : 1);     // rows per 256-byte bank row
+  // largest window over the allowed tile shapes (TW = 8 .. 64)
+  static constexpr int ws(int tw) { return (S * (TP / tw - 1) + KS) * (S * (tw - 1) + KS); }
+  static constexpr int mx(int a, int b) { return a > b ? a : b; }
+  static constexpr int WS_MAX = mx(mx(ws(8), ws(16)), mx(ws(32), ws(64)));
+  static constexpr int WROUNDS = (WS_MAX * P + 511) / 512;            // 16-byte pieces / 512 lanes
+  static constexpr int WIN_BYTES = WROUNDS * 8192;
+};
+
+__device__ __forceinline__ float cb_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+template <int KS, int S, int KC, int NPF, int NA>
+__global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
+  using G = CbGeom<KS, S, KC, NPF>;
+  constexpr int TC = NA * 32, TAPS = G::TAPS, KSTEPS = G::KSTEPS, P = G::P, ROWB = G::ROWB, LOG_R = G::LOG_R;
+  constexpr int PAD = KS / 2;
+  constexpr int WIMG = TAPS * TC * ROWB;                               // weight image bytes per (cout tile, chunk)
+  constexpr int AROUNDS = (WIMG + 8191) / 8192;
+  constexpr int STAGE = G::WIN_BYTES + AROUNDS * 8192;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  int pt, ct;
+  xcd_remap(blockIdx.x, a.n_ct, pt, ct);
+  if (pt >= a.n_rt * a.n_xt) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int TW = 1 << a.log_tw, TR = G::TP >> a.log_tw;
+  const int WC = S * (TW - 1) + KS, WR = S * (TR - 1) + KS, WS = WR * WC;
+  const int rt = pt / a.n_xt, xt = pt - rt * a.n_xt;
+  const int R0 = rt * TR, x0 = xt * TW;
+  const int Hop = a.Ho + 1, Hp = a.H + 1;
+  // input row (stacked space) of the first tap row of output row R:  (R / Hop) * Hp + S * (R % Hop) - PAD
+  const int inrow_base = (R0 / Hop) * Hp + S * (R0 % Hop) - PAD;
+  const int xin_base = S * x0 - PAD;
+
+  // ---- per-lane window DMA offsets (chunk-invariant) --------------------------------------------------------
+  unsigned woff[G::WROUNDS];
+#pragma unroll
+  for (int t = 0; t < G::WROUNDS; ++t) {
+    const int pi = t * 512 + tid;
+    const int slot = pi / P, pp = pi - slot * P;
+    unsigned off = 0x80000000u;
+    if (slot < WS) {
+      const int wr = slot / WC, wc = slot - wr * WC;
+      const int Rin = inrow_base + wr, x = xin_base + wc;
+      if (Rin >= 0 && (unsigned)x < (unsigned)a.W) {
+        const int n = Rin / Hp, y = Rin - n * Hp;
+        if (n < a.N && y < a.H) {
+          const int piece = pp ^ ((slot >> LOG_R) & (P - 1));
+          off = (unsigned)(((((long)n * a.H + y) * a.W + x) * a.ldx + piece * 8) * 2);
+        }
+      }
+    }
+    woff[t] = off;
+  }
+  unsigned aoffw[AROUNDS];
+#pragma unroll
+  for (int t = 0; t < AROUNDS; ++t) {
+    const int e = (t * 512 + tid) * 16;
+    aoffw[t] = e < WIMG ? (unsigned)e : 0x80000000u;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), (short)0, (int)a.wt_bytes, 0x00020000);
+#endif
+  auto stage = [&](int kc, int st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned char* wdst = smem + st * STAGE + wave * 1024;
+    unsigned char* adst = wdst + G::WIN_BYTES;
+#pragma unroll
+    for (int t = 0; t < G::WROUNDS; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * 8192), 16, woff[t], kc * ROWB, 0, 0);
+#pragma unroll
+    for (int t = 0; t < AROUNDS; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * 8192), 16, aoffw[t],
+                                               (ct * a.nchunks + kc) * WIMG, 0, 0);
+#endif
+  };
+
+  // ---- per-lane output positions and LDS fragment addresses -----------------------------------------------------
+  int pn[NPF], prem[NPF];                       // image index, yo * Wo + xo (or -1)
+  unsigned baddr[TAPS * KSTEPS][NPF];
+#pragma unroll
+  for (int f = 0; f < NPF; ++f) {
+    const int i = (wave * NPF + f) * 32 + r;
+    const int tr = i >> a.log_tw, tc = i & (TW - 1);
+    const int Rout = R0 + tr, xo = x0 + tc;
+    const int n = Rout / Hop, yo = Rout - n * Hop;
+    pn[f] = n;
+    prem[f] = (n < a.N && yo < a.Ho && xo < a.Wo) ? yo * a.Wo + xo : -1;
+    const int wr = (n * Hp + S * yo - PAD) - inrow_base, wc = S * tc;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int slot = (wr + t / KS) * WC + wc + t % KS;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s)
+        baddr[t * KSTEPS + s][f] = (unsigned)(slot * ROWB + (((2 * s + h) ^ ((slot >> LOG_R) & (P - 1))) << 4));
+    }
+  }
+  unsigned aaddr[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) aaddr[s] = (unsigned)(r * ROWB + (((2 * s + h) ^ ((r >> LOG_R) & (P - 1))) << 4));
+
+  f32x16 acc[NA][NPF];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int f = 0; f < NPF; ++f)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
+
+  stage(0, 0);
+  for (int kc = 0; kc < a.nchunks; ++kc) {
+    const int st = kc & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kc + 1 < a.nchunks) stage(kc + 1, st ^ 1);
+    const unsigned char* Ws = smem + st * STAGE;
+    const unsigned char* As = Ws + G::WIN_BYTES;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        bf16x8 af[NA], bfr[NPF];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr[s]);
+#pragma unroll
+        for (int f = 0; f < NPF; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(Ws + baddr[t * KSTEPS + s][f]);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+          for (int f = 0; f < NPF; ++f)
+            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[f], acc[i][f], 0, 0, 0);
+      }
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31 (position), row = (q & 3) + 8 (q >> 2) + 4 h (output channel) ----------
+  const long HWo = (long)a.Ho * a.Wo;
+#pragma unroll
+  for (int f = 0; f < NPF; ++f) {
+    if (prem[f] < 0) continue;
+    const long pix = (long)pn[f] * HWo + prem[f];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
+        if (co0 >= a.Cout) continue;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[i][f][4 * g4 + j] + bv[j];
+        if (a.res) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + pix * a.ldr + co0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+        }
+        if (a.out_mode == 0) {
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + pix * a.ldy + co0) = __builtin_convertvector(v, bf16x4);
+        } else if (a.out_mode == 2) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pix * a.ldy + co0) = v;
+        } else {
+          float* yb = reinterpret_cast<float*>(a.y) + ((long)pn[f] * a.Cout + co0) * HWo + prem[f];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co0 + j < a.Cout) yb[j * HWo] = (co0 + j < a.nsig) ? cb_sigmoid(v[j]) : v[j];
+        }
+      }
+  }
+}
+
+template <int KS, int S, int KC, int NPF, int NA>
+static int cb_launch(CbArgs& a, hipStream_t st) {
+  using G = CbGeom<KS, S, KC, NPF>;
+  constexpr int WIMG = KS * KS * NA * 32 * KC * 2;
+  constexpr int LDS = 2 * (G::WIN_BYTES + ((WIMG + 8191) / 8192) * 8192);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA>;
+  static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
+  bool& done = attr_by_dev[sgta_device_slot()];
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return SGTA_EBADARG;
+    done = true;
+  }
+  const int n_pt = a.n_rt * a.n_xt;
+  const int grid = cdiv(n_pt, 8) * 8 * a.n_ct;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a);
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}
+
+// x: bf16 NHWC [N,H,W,ldx] (pointer at the first input channel of the view; x_bytes = bytes from x to the end of the
+// allocation that may be addressed, < 2^31); wt: sgta_conv_bf16_pack layout for (ks, stride, kc, na); bias f32
+// [n_ct*32*na]; res: bf16 NHWC [N,Ho,Wo,ldr] or NULL (added before the activation); out_mode 0: y bf16 NHWC [..,ldy],
+// 2: y f32 NHWC [..,ldy], 1: y f32 NCHW [N,Cout,Ho,Wo] with sigmoid on channels < nsig.  act: 0 none, 1 ReLU.
+// log_tw: log2 of the tile width (3..6).  Cin % kc == 0, kc in {16 (3x3), 32 (1x1)}.
+extern "C" int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt_bytes, const float* bias,
+                              const void* res, int ldr, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
+                              int ks, int stride, int kc, int na, int log_tw, int act, int out_mode, int nsig,
+                              hipStream_t st) {
+  if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SGTA_EBADARG;
+  if (x_bytes <= 0 || x_bytes > 0x7fffffffL || wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
+  if (Cin % kc || (ldx % 8) || log_tw < 3 || log_tw > 6 || act < 0 || act > 1 || out_mode < 0 || out_mode > 2) return SGTA_EBADARG;
+  if (out_mode != 1 && (ldy % 4 || Cout % 4)) return SGTA_EBADARG;
+  if (res && ldr % 4) return SGTA_EBADARG;
+  CbArgs a;
+  a.x = x; a.x_bytes = x_bytes; a.ldx = ldx; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
+  a.res = reinterpret_cast<const __bf16*>(res); a.ldr = ldr; a.y = y; a.ldy = ldy;
+  a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cout = Cout;
+  a.nchunks = Cin / kc; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act; a.out_mode = out_mode; a.nsig = nsig;
+  const int npf = (ks == 3 && stride == 2) ? 1 : 2;
+  const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
+  a.n_rt = cdiv((long)N * (a.Ho + 1), TR);
+  a.n_xt = cdiv(a.Wo, TW);
+  if (ks == 3 && stride == 1 && kc == 16) {
+    if (na == 1) return cb_launch<3, 1, 16, 2, 1>(a, st);
+    if (na == 2) return cb_launch<3, 1, 16, 2, 2>(a, st);
+    if (na == 4) return cb_launch<3, 1, 16, 2, 4>(a, st);
+  } else if (ks == 3 && stride == 2 && kc == 16) {
+    if (na == 1) return cb_launch<3, 2, 16, 1, 1>(a, st);
+    if (na == 2) return cb_launch<3, 2, 16, 1, 2>(a, st);
+  } else if (ks == 1 && stride == 1 && kc == 32) {
+    if (na == 1) return cb_launch<1, 1, 32, 2, 1>(a, st);
+    if (na == 2) return cb_launch<1, 1, 32, 2, 2>(a, st);
+    if (na == 4) return cb_launch<1, 1, 32, 2, 4>(a, st);
+  }
+  return SGTA_EBADARG;
+}

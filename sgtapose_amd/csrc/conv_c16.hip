@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
 // of 4), the heat-map conv k = tap (49 -> 13 k-steps); MFMA k-slot g of step s takes k = 4s + g, so each
 // lane keeps the window offset of ITS k in a register (37 + 13 registers) -- no zero-padded channel
 // slots: 50 MFMAs per 16 pixels instead of 98.
+// NHWC_BF16: the bf16 data path's stem -- same arithmetic (fp32 inputs, f32 MFMA), output rounded to bf16 and written
+// channels-last [B,H,W,ldy] (a lane holds 4 consecutive output channels of its pixel: one 8-byte store; a.y_bs = ldy)
+template <bool NHWC_BF16>
 __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
   constexpr int KS = 7, TH = 8, TW = 32, KK = 49, P = 3;
   constexpr int WH = TH + KS - 1, WW = TW + KS - 1;
@@ -218,6 +221,18 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
   for (int n = 0; n < 4; ++n) {
     const int y = ty0 + 2 * wave + (n >> 1), x = tx0 + (n & 1) * 16 + c16;
     if (y >= H || x >= W) continue;
+    if (NHWC_BF16) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * g + r;
+        v[r] = fmaxf(acc[0][n][r] + a.bias[co], 0.0f) + fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
+      }
+      __bf16* yh = reinterpret_cast<__bf16*>(a.y) + (((long)b * H + y) * W + x) * a.y_bs + 4 * g;
+      *reinterpret_cast<bf16x4*>(yh) = __builtin_convertvector(v, bf16x4);
+      continue;
+    }
     float* yb = a.y + (long)b * a.y_bs + y * W + x;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -237,9 +252,21 @@ extern "C" int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, lon
   if (mode == 0)                                   // level0: 3x3, 16 -> 16, BN + ReLU
     hipLaunchKernelGGL((conv_c16_kernel<3, 4, false>), dim3(grid), dim3(256), 0, st, a);
   else if (mode == 1 && x2)                        // fused stems: 7x7 (3 -> 16) and (1 -> 16)
-    hipLaunchKernelGGL(stem_c16_kernel, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(stem_c16_kernel<false>, dim3(grid), dim3(256), 0, st, a);
   else
     return SGTA_EBADARG;
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}
+
+// bf16 data path: the fused 7x7 stems (dla.py:259-270, :324-328) with fp32 NCHW inputs (the boundary's images and prior
+// maps) and a bf16 channels-last output y [B,H,W,ldy] (16 channels written at y).
+extern "C" int sgta_stem_bf16(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt, const float* bias,
+                              void* y, int ldy, int B, int H, int W, hipStream_t st) {
+  if (!x || !x2 || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0 || ldy < 16 || ldy % 4) return SGTA_EBADARG;
+  if ((long)16 * H * W > 0x7fffffffL) return SGTA_EBADARG;
+  C16Args a{x, x_bs, x2, x2_bs, wt, bias, reinterpret_cast<float*>(y), (long)ldy, B, H, W, cdiv(W, 32), cdiv(H, 8)};
+  hipLaunchKernelGGL(stem_c16_kernel<true>, dim3(B * a.tiles_x * a.tiles_y), dim3(256), 0, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

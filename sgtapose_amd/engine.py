@@ -399,13 +399,18 @@ class Engine:
                             self.last_fid0 = t01[1]
             for i in (2, 3, 4, 5):
                 self.temporal_scatter(lv[i], B, tok.get(i) or self.temporal_tokens(lv[i], i, idx, B))
-            cur = [View(v.base[B:]) for v in lv]
+            cur = [self._frame(v, 1, B) for v in lv]
             feat = self.neck(cur)
             self.last_feat = feat
             out = self.heads(feat, hm_act, static)
             if dead_on_side:
                 main.wait_stream(side)             # the step is complete only when the side work is
             return out
+
+    @staticmethod
+    def _frame(v, k, B):
+        """Frame ``k`` (0 = oldest) of a level whose batch holds the frames back to back."""
+        return View(v.base[k * B:(k + 1) * B])
 
     def _neck_stream(self):
         if getattr(self, "_side2", None) is None:

@@ -1,0 +1,240 @@
+"""bf16 data path of ``DLAPlanAWindowL3New.forward`` (BASELINE configs[2]; same call stack as engine.py).
+
+Feature maps are bf16 CHANNELS-LAST [N,H,W,C] in HBM (half the bytes of the fp32 path, and the layout in which
+both the MFMA operand of a pixel and a deformable-sampling corner are one contiguous 16-byte run); weights are bf16;
+every product runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (direct-form convs: at the bf16 matrix rate the
+path is memory-bound, so Winograd is neither needed nor numerically wise).  fp32 stays where the reference's
+numerics are fragile or the data are tiny: the boundary inputs and the two 7x7 stems that read them, the DCN
+offset / mask maps and sampling arithmetic, the whole windowed attention stage (a few hundred token rows: QKV / softmax
+/ LayerNorm / FFN / cat-MLP run in the fp32 token kernels, tokens are converted at the gather / scatter), the head
+outputs and the decode.  The API boundary (inputs, output dict, decode dictionary) is unchanged.
+"""
+import torch
+
+from . import _lib, ops, ops_bf16 as bops
+from .engine import Engine, _bn_tuple
+from .ops import ACT_NONE, ACT_RELU
+from .ops_bf16 import BF16, PackedConvBF16, PackedDCNBF16, ViewH
+
+
+class EngineBF16(Engine):
+    dtype = "bf16"
+
+    # ------------------------------------------------------------------------------------------
+    def _pack(self, m):
+        P = {}
+        b = m.base
+        P["stem.c16"] = ops.PackedC16(b.pre_img_layer[0].weight, _bn_tuple(b.pre_img_layer[1]),
+                                       b.pre_hm_layer[0].weight, _bn_tuple(b.pre_hm_layer[1]))
+        P["level0"] = PackedConvBF16(b.level0[0].weight, None, _bn_tuple(b.level0[1]))
+        P["level1"] = PackedConvBF16(b.level1[0].weight, None, _bn_tuple(b.level1[1]), stride=2)
+
+        def pack_tree(node, name):
+            if node.levels == 1:
+                for t in ("tree1", "tree2"):
+                    blk = getattr(node, t)
+                    P["%s.%s.conv1" % (name, t)] = PackedConvBF16(blk.conv1.weight, None, _bn_tuple(blk.bn1), stride=blk.stride)
+                    P["%s.%s.conv2" % (name, t)] = PackedConvBF16(blk.conv2.weight, None, _bn_tuple(blk.bn2))
+                P[name + ".root"] = PackedConvBF16(node.root.conv.weight, None, _bn_tuple(node.root.bn))
+                if hasattr(node, "project"):
+                    P[name + ".project"] = PackedConvBF16(node.project[0].weight, None, _bn_tuple(node.project[1]))
+            else:
+                pack_tree(node.tree1, name + ".tree1")
+                pack_tree(node.tree2, name + ".tree2")
+
+        for lv in range(2, 6):
+            pack_tree(getattr(b, "level%d" % lv), "level%d" % lv)
+
+        def pack_ida(ida, name):
+            for j in range(1, len(ida.channels)):
+                for kind in ("proj", "node"):
+                    dc = getattr(ida, "%s_%d" % (kind, j))
+                    com = dc.conv.conv_offset_mask
+                    P["%s.%s_%d.om" % (name, kind, j)] = PackedConvBF16(com.weight, com.bias, cout_pad_to=32)
+                    P["%s.%s_%d" % (name, kind, j)] = PackedDCNBF16(dc.conv.weight, dc.conv.bias, _bn_tuple(dc.actf[0]))
+                P["%s.up_%d" % (name, j)] = bops.pack_up_weight(getattr(ida, "up_%d" % j).weight)
+
+        for i in range(3):
+            pack_ida(getattr(m.dla_up, "ida_%d" % i), "dla_up.ida_%d" % i)
+        pack_ida(m.ida_up, "ida_up")
+
+        f = lambda t: t.detach().float().contiguous()          # noqa: E731
+        self.tf = [self._pack_encoder(m.transformer[i]) for i in range(3)] if hasattr(m, "transformer") else []
+        self.cat = [dict(w0=f(s[0].weight), b0=f(s[0].bias), w2=f(s[2].weight), b2=f(s[2].bias)) for s in m.cat_layer]
+
+        self.head_names = [h for h in m.heads if hasattr(m, h)]
+        hw = torch.cat([getattr(m, h)[0].weight.detach().float() for h in self.head_names], 0)
+        hb = torch.cat([getattr(m, h)[0].bias.detach().float() for h in self.head_names], 0)
+        P["heads.0"] = PackedConvBF16(hw, hb)
+        self.head_hidden = [getattr(m, h)[0].out_channels for h in self.head_names]
+        for h in self.head_names:
+            P["heads.2." + h] = PackedConvBF16(getattr(m, h)[2].weight, getattr(m, h)[2].bias)
+        self.P = P
+
+    def hbuf(self, name, n, h, w, c, dtype=BF16):
+        return ViewH(self.buf(name, (n, h, w, c), dtype))
+
+    @staticmethod
+    def _frame(v, k, B):
+        return v.images(k * B, (k + 1) * B)
+
+    # ------------------------------------------------------------------------------------------
+    def _tree_l1(self, node, name, x, out, cat, bottom=None):
+        P, c, cin, N = self.P, node.cout, node.cin, x.N
+        h, w = x.H // node.stride, x.W // node.stride
+        if node.stride > 1:
+            if bottom is None:
+                bottom = cat.slice(2 * c, cin) if node.level_root else self.hbuf("pool", N, h, w, cin)
+                bops.maxpool2(x, bottom)
+        else:
+            bottom = x
+        if cin != c:
+            residual = self.hbuf("proj", N, h, w, c)
+            bops.conv(bottom, P[name + ".project"], residual, ACT_NONE)
+        else:
+            residual = bottom
+        a = self.hbuf("blk_a", N, h, w, c)
+        x1, x2 = cat.slice(c, c), cat.slice(0, c)
+        bops.conv(x, P[name + ".tree1.conv1"], a, ACT_RELU)
+        bops.conv(a, P[name + ".tree1.conv2"], x1, ACT_RELU, res=residual)
+        bops.conv(x1, P[name + ".tree2.conv1"], a, ACT_RELU)
+        bops.conv(a, P[name + ".tree2.conv2"], x2, ACT_RELU, res=x1)
+        bops.conv(cat, P[name + ".root"], out, ACT_RELU)
+        return out
+
+    def _tree(self, node, name, x, out, bottom=None):
+        N, c, cin = x.N, node.cout, node.cin
+        h, w = x.H // node.stride, x.W // node.stride
+        if node.levels == 1:
+            cat = self.hbuf(name + ".cat", N, h, w, node.root_dim)
+            if bottom is not None and node.level_root:
+                bottom = None
+            return self._tree_l1(node, name, x, out, cat, bottom=bottom)
+        inner = node.tree2
+        cat2 = self.hbuf(name + ".cat2", N, h, w, inner.root_dim)
+        bottom = cat2.slice(2 * c, cin)
+        bops.maxpool2(x, bottom)
+        t1 = cat2.slice(2 * c + cin, c)
+        cat1 = self.hbuf(name + ".cat1", N, h, w, node.tree1.root_dim)
+        self._tree_l1(node.tree1, name + ".tree1", x, t1, cat1, bottom=bottom)
+        return self._tree_l1(inner, name + ".tree2", t1, out, cat2)
+
+    def backbone_frames(self, frames, after_level=None):
+        B, _, H, W = frames[-1][0].shape
+        N = len(frames) * B
+        P = self.P
+        s = self.hbuf("stem", N, H, W, 16)
+        for k, (img, hm) in enumerate(frames):
+            bops.stem(img, hm, P["stem.c16"], s.images(k * B, (k + 1) * B))
+        lv = [self.hbuf("l0", N, H, W, 16)]
+        bops.conv(s, P["level0"], lv[0], ACT_RELU)
+        if after_level:
+            after_level(0, lv[0])
+        lv.append(self.hbuf("l1", N, H // 2, W // 2, 32))
+        bops.conv(lv[0], P["level1"], lv[1], ACT_RELU)
+        if after_level:
+            after_level(1, lv[1])
+        ch = self.model.base.channels
+        for i in range(2, 6):
+            out = self.hbuf("l%d" % i, N, H >> i, W >> i, ch[i])
+            self._tree(getattr(self.model.base, "level%d" % i), "level%d" % i, lv[i - 1], out)
+            lv.append(out)
+            if after_level:
+                after_level(i, out)
+        return lv
+
+    # ------------------------------------------------------------------------------------------
+    def temporal_tokens(self, feats, i, idx, B):
+        """As Engine.temporal_tokens; tokens are fp32 (converted from the bf16 map by the gather)."""
+        K = self.num_classes
+        C, H, W = feats.C, feats.H, feats.W
+        pre_f, cur_f = feats.images(0, B), feats.images(B, 2 * B)
+        n = K * (1 + 2 * (self.ks[i] // 2)) ** 2
+        fid, win = ops.window_index(idx, float(self.scales[i]), self.ks[i], H, W,
+                                    self.buf("fid%d" % i, (2, B, n), torch.int64),
+                                    self.buf("win%d" % i, (B, n), torch.uint8))
+        M = B * n
+        cat_tok = self.buf("cat_tok%d" % i, (M, 2 * C))
+        bops.window_gather(cur_f, fid[1], cat_tok, col0=C)
+        if i <= 2:
+            T = self.tf[i]
+            hid = T["hid"]
+            key = self.buf("key%d" % i, (M, C))
+            cur = self.buf("qry%d" % i, (M, C))
+            bops.window_gather(pre_f, fid[0], key)
+            bops.window_gather(cur_f, fid[1], cur)
+            kv = ops.linear(key, T["wkv"], None, self.buf("kv%d" % i, (M, 2 * hid)))
+            q = self.buf("q%d" % i, (M, hid))
+            att = self.buf("att%d" % i, (M, hid))
+            y1 = self.buf("y1_%d" % i, (M, C))
+            nxt = self.buf("qry_b%d" % i, (M, C))
+            for it in range(3):
+                ops.linear(cur, T["wq"], None, q)
+                ops.mhca(q, kv[:, :hid], kv[:, hid:], T["pos"], att, B, n, 8, hid // 8)
+                ops.linear(att, T["fc_w"], T["fc_b"], y1, res=cur, ln=T["ln1"])
+                dst = cat_tok[:, :C] if it == 2 else nxt
+                if ops.ffn_ln(y1, T["w1"], T["b1"], T["w2"], T["b2"], T["ln3"], dst) is None:
+                    hdn = self.buf("ffn%d" % i, (M, 1024))
+                    ops.linear(y1, T["w1"], T["b1"], hdn, relu=True)
+                    ops.linear(hdn, T["w2"], T["b2"], dst, res=y1, ln=T["ln3"])
+                cur, nxt = dst, cur
+        else:
+            bops.window_gather(pre_f, fid[0], cat_tok, col0=0)
+        Cc = self.cat[i]
+        h1 = ops.linear(cat_tok, Cc["w0"], Cc["b0"], self.buf("cat_h%d" % i, (M, 4 * C)), relu=True)
+        z = ops.linear(h1, Cc["w2"], Cc["b2"], self.buf("cat_z%d" % i, (M, C)))
+        return z, fid, win
+
+    def temporal_scatter(self, feats, B, tok):
+        z, fid, win = tok
+        bops.window_scatter(z, fid[1], win, feats.images(B, 2 * B))
+
+    # ------------------------------------------------------------------------------------------
+    def _deform(self, name, x, out, om_name="om"):
+        om = self.hbuf(om_name, x.N, x.H, x.W, 32, torch.float32)
+        bops.conv(x, self.P[name + ".om"], om, ACT_NONE, out_mode=bops.OUT_F32_NHWC)
+        return bops.dcn_v2(x, om, self.P[name], out, ACT_RELU)
+
+    def _ida(self, ida, name, layers, startp, endp):
+        main = torch.cuda.current_stream()
+        side = self._neck_stream() if (self.use_side_stream and _lib.PROFILE is None and endp - startp > 2) else None
+        early = {}
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for i in range(startp + 2, endp):
+                    j = i - startp
+                    x = layers[i]
+                    p = self._deform("%s.proj_%d" % (name, j), x, self.hbuf("%s.p%d" % (name, j), x.N, x.H, x.W, ida.o),
+                                     om_name="%s.om%d" % (name, j))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    early[i] = (p, ev)
+        for i in range(startp + 1, endp):
+            j = i - startp
+            x = layers[i]
+            o = ida.o
+            f = ida.up_f[j]
+            if i in early:
+                p, ev = early[i]
+                main.wait_event(ev)
+            else:
+                p = self._deform("%s.proj_%d" % (name, j), x, self.hbuf("ida_p", x.N, x.H, x.W, o))
+            u = bops.upsample_add(p, self.P["%s.up_%d" % (name, j)], layers[i - 1],
+                                  self.hbuf("ida_u", x.N, x.H * f, x.W * f, o), f)
+            layers[i] = self._deform("%s.node_%d" % (name, j), u, self.hbuf("%s.n%d" % (name, j), x.N, u.H, u.W, o))
+
+    def heads(self, feat, hm_act=ACT_NONE, static=False):
+        B, h, w = feat.N, feat.H, feat.W
+        hidden = self.hbuf("head_hidden", B, h, w, sum(self.head_hidden))
+        bops.conv(feat, self.P["heads.0"], hidden, ACT_RELU)
+        out, off = {}, 0
+        for name, hc in zip(self.head_names, self.head_hidden):
+            pc = self.P["heads.2." + name]
+            o = self.buf("out_" + name, (B, pc.Cout, h, w)) if static else \
+                torch.empty((B, pc.Cout, h, w), dtype=torch.float32, device=self.dev)
+            nsig = pc.Cout if (name == "hm" and hm_act == ops.ACT_SIGMOID) else 0
+            bops.conv(hidden.slice(off, hc), pc, o, ACT_NONE, out_mode=bops.OUT_F32_NCHW, nsig=nsig)
+            out[name] = o
+            off += hc
+        return out

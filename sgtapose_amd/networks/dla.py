@@ -234,10 +234,27 @@ class DLAPlanAWindowL3New(nn.Module):
             raise RuntimeError("the HIP path is inference-only: call model.eval() (sgta_detector.py:54)")
         return [self.engine().forward(x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls)]
 
+    # 'f32' (the reference's arithmetic, BASELINE configs[1]) or 'bf16' (configs[2]: bf16 feature maps / weights on bf16
+    # MFMA, fp32 accumulate / softmax / LayerNorm / decode); also read from opt.compute_dtype at construction
+    @property
+    def engine_dtype(self):
+        return getattr(self, "_engine_dtype", getattr(self.opt, "compute_dtype", "f32"))
+
+    @engine_dtype.setter
+    def engine_dtype(self, v):
+        if v not in ("f32", "bf16"):
+            raise ValueError("engine_dtype must be 'f32' or 'bf16'")
+        object.__setattr__(self, "_engine_dtype", v)
+        self._engine = None
+
     def engine(self):
         if self._engine is None:
-            from ..engine import Engine
-            self._engine = Engine(self)
+            if self.engine_dtype == "bf16":
+                from ..engine_bf16 import EngineBF16
+                self._engine = EngineBF16(self)
+            else:
+                from ..engine import Engine
+                self._engine = Engine(self)
         return self._engine
 
     def invalidate(self):

@@ -1,0 +1,236 @@
+"""Python faces of the bf16 data path (BASELINE configs[2]): bf16 NHWC feature maps and bf16 weights on
+v_mfma_f32_32x32x16_bf16, fp32 accumulation; everything that leaves the bf16 domain (DCN offsets / masks, head outputs,
+attention tokens, decode) is fp32.  torch is plumbing only; every function enqueues hand-written HIP kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import ACT_NONE, ACT_RELU, fold_bn, _round_up, _stream  # noqa: F401
+
+OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+BF16 = torch.bfloat16
+
+
+class ViewH:
+    """A [N, H, W, C] bfloat16 (or float32) channels-last activation that may be a channel slice of a wider buffer."""
+    __slots__ = ("base", "c0", "C")
+
+    def __init__(self, base, c0=0, C=None):
+        if not (base.is_cuda and base.is_contiguous() and base.dim() == 4):
+            raise _lib.SgtaHipError("expected a contiguous [N,H,W,C] tensor on the GPU")
+        self.base = base
+        self.c0 = c0
+        self.C = base.shape[3] - c0 if C is None else C
+        assert 0 <= c0 and c0 + self.C <= base.shape[3]
+
+    N = property(lambda s: s.base.shape[0])
+    H = property(lambda s: s.base.shape[1])
+    W = property(lambda s: s.base.shape[2])
+    ld = property(lambda s: s.base.shape[3])
+    esize = property(lambda s: s.base.element_size())
+    ptr = property(lambda s: s.base.data_ptr() + s.c0 * s.base.element_size())
+    nbytes = property(lambda s: (s.base.numel() - s.c0) * s.base.element_size())      # addressable from ptr
+
+    def tensor(self):
+        return self.base[..., self.c0:self.c0 + self.C]
+
+    def slice(self, c0, C):
+        return ViewH(self.base, self.c0 + c0, C)
+
+    def images(self, lo, hi):
+        """Sub-batch [lo, hi) (a view of the same memory)."""
+        return ViewH(self.base[lo:hi], self.c0, self.C)
+
+
+def _swizzle_rows(img, KC):
+    """img [..., rows, KC] -> the LDS image of conv_bf16.hip / dcn_bf16.hip: 16-byte pieces (8 k) of row ``r`` stored at
+    piece ^ ((r >> log_r) & (P - 1)) (conflict-free ds_read_b128 fragment reads)."""
+    P = KC // 8
+    log_r = {16: 3, 32: 2, 64: 1}[KC]
+    rows = img.shape[-2]
+    v = img.reshape(*img.shape[:-1], P, 8)
+    r = torch.arange(rows, device=img.device)
+    src = (torch.arange(P, device=img.device)[None, :] ^ ((r[:, None] >> log_r) & (P - 1)))       # [rows, P]
+    idx = src.view(*([1] * (v.dim() - 3)), rows, P, 1).expand_as(v)
+    return torch.gather(v, -2, idx).reshape(img.shape)
+
+
+class PackedConvBF16:
+    """bf16 weights of one conv in the [cout tile][chunk][tap][TC][KC] LDS-image layout of sgta_conv_bf16, BN folded."""
+
+    def __init__(self, weight, bias=None, bn=None, stride=1, cout_pad_to=None):
+        w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
+        co, ci, ks, _ = w.shape
+        if cout_pad_to is not None and cout_pad_to > co:                 # e.g. the 27-channel offset / mask conv -> 32
+            w = torch.cat([w, w.new_zeros(cout_pad_to - co, ci, ks, ks)], 0)
+            b = torch.cat([b, b.new_zeros(cout_pad_to - co)], 0)
+            co = cout_pad_to
+        assert ks in (1, 3) and stride in (1, 2) and not (ks == 1 and stride == 2)
+        self.Cout, self.Cin, self.ks, self.stride = co, ci, ks, stride
+        self.kc = 16 if ks == 3 else 32
+        if ci % self.kc:
+            raise _lib.SgtaHipError("bf16 conv needs Cin %% %d == 0, got %d" % (self.kc, ci))
+        na = 1 if co <= 32 else (2 if co <= 64 else 4)
+        if stride == 2:
+            na = min(na, 2)
+        self.na, self.TC = na, 32 * na
+        n_ct = -(-co // self.TC)
+        taps, nch = ks * ks, ci // self.kc
+        wp = w.new_zeros(n_ct * self.TC, ci, taps)
+        wp[:co] = w.reshape(co, ci, taps)
+        img = wp.view(n_ct, self.TC, nch, self.kc, taps).permute(0, 2, 4, 1, 3).contiguous()    # [ct][chunk][tap][TC][KC]
+        self.wt = _swizzle_rows(img, self.kc).to(BF16).contiguous()
+        bb = b.new_zeros(n_ct * self.TC)
+        bb[:co] = b
+        self.bias = bb.float().contiguous()
+        self.w_ref = w.to(BF16)                   # tests: the rounded weights, [Cout, Cin, ks, ks]
+
+    def tile_log_tw(self, N, Ho, Wo):
+        """log2 of the tile width that wastes the fewest positions (ties: the wider tile = longer contiguous DMA rows)."""
+        tp = 256 if (self.ks == 3 and self.stride == 2) else 512
+        best = None
+        for ltw in (6, 5, 4, 3):
+            tw = 1 << ltw
+            tr = tp // tw
+            work = (-(-Wo // tw) * tw) * (-(-(N * (Ho + 1)) // tr) * tr)
+            if best is None or work < best[1]:
+                best = (ltw, work)
+        return best[0]
+
+    def flops(self, M):
+        return 2.0 * M * self.Cout * self.Cin * self.ks * self.ks
+
+
+def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cout=None):
+    """out = act(conv(x) + bias [+ res]).  x: ViewH (bf16); out: ViewH (bf16 NHWC / f32 NHWC) or a contiguous f32 NCHW
+    tensor (out_mode = OUT_F32_NCHW, sigmoid on channels < nsig); res: ViewH bf16 at the output resolution."""
+    assert x.base.dtype == BF16 and x.C == pc.Cin
+    Ho, Wo = (x.H - 1) // pc.stride + 1, (x.W - 1) // pc.stride + 1
+    cout = pc.Cout if cout is None else cout
+    if out_mode == OUT_F32_NCHW:
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (x.N, cout, Ho, Wo)
+        yptr, ldy = out.data_ptr(), 0
+    else:
+        assert out.base.dtype == (BF16 if out_mode == OUT_BF16_NHWC else torch.float32)
+        assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cout)
+        yptr, ldy = out.ptr, out.ld
+    rp, ldr = None, 0
+    if res is not None:
+        assert res.base.dtype == BF16 and (res.N, res.H, res.W, res.C) == (x.N, Ho, Wo, cout)
+        rp, ldr = res.ptr, res.ld
+    meta = None
+    if _lib.PROFILE is not None:
+        M = x.N * Ho * Wo
+        meta = {"kernel": "conv_bf16_kernel<%d,%d,%d>" % (pc.ks, pc.stride, pc.na), "flops": pc.flops(M),
+                "exec_flops": pc.flops(M),
+                "bytes": 2.0 * (pc.Cin * x.N * x.H * x.W + pc.Cout * pc.Cin * pc.ks ** 2) + (2.0 if out_mode == 0 else 4.0) * cout * M}
+    _lib.call("sgta_conv_bf16", x.ptr, x.nbytes, x.ld, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
+              rp, ldr, yptr, ldy, x.N, x.H, x.W, pc.Cin, cout, pc.ks, pc.stride, pc.kc, pc.na,
+              pc.tile_log_tw(x.N, Ho, Wo), act, out_mode, nsig, _stream(), meta=meta)
+    return out
+
+
+class PackedDCNBF16:
+    """bf16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][tap][Cin/64][TC][64], BN folded."""
+
+    def __init__(self, weight, bias=None, bn=None):
+        w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
+        co, ci, ks, _ = w.shape
+        assert ks == 3
+        if ci % 64 or co % 4:
+            raise _lib.SgtaHipError("bf16 DCN needs Cin %% 64 == 0 and Cout %% 4 == 0, got %d -> %d" % (ci, co))
+        self.Cout, self.Cin = co, ci
+        self.na = 2 if co <= 64 else 4
+        self.TC = 32 * self.na
+        n_ct = -(-co // self.TC)
+        ng = ci // 64
+        wp = w.new_zeros(n_ct * self.TC, ci, 9)
+        wp[:co] = w.reshape(co, ci, 9)
+        img = wp.view(n_ct, self.TC, ng, 64, 9).permute(0, 4, 2, 1, 3).contiguous()       # [ct][tap][group][TC][64]
+        self.wt = _swizzle_rows(img, 64).to(BF16).contiguous()
+        bb = b.new_zeros(n_ct * self.TC)
+        bb[:co] = b
+        self.bias = bb.float().contiguous()
+        self.w_ref = w.to(BF16)
+
+    def tile_log_tw(self, N, H, W):
+        tp = 512 if self.na == 2 else 256
+        best = None
+        for ltw in (6, 5, 4, 3):
+            tw = 1 << ltw
+            tr = tp // tw
+            work = (-(-W // tw) * tw) * (-(-(N * H) // tr) * tr)
+            if best is None or work < best[1]:
+                best = (ltw, work)
+        return best[0]
+
+    def flops(self, M):
+        return 2.0 * M * self.Cout * self.Cin * 9
+
+
+def dcn_v2(x, om, pc, out, act=ACT_RELU):
+    """x: ViewH bf16; om: ViewH float32 (>= 27 channels: the raw offset / mask conv output); out: ViewH bf16."""
+    assert x.base.dtype == BF16 and om.base.dtype == torch.float32 and out.base.dtype == BF16
+    assert x.C == pc.Cin and out.C == pc.Cout and om.C >= 27 and x.c0 % 8 == 0
+    assert (om.N, om.H, om.W) == (x.N, x.H, x.W) == (out.N, out.H, out.W)
+    meta = None
+    if _lib.PROFILE is not None:
+        M = x.N * x.H * x.W
+        meta = {"kernel": "dcn_bf16_kernel<%d>" % pc.na, "flops": pc.flops(M), "exec_flops": pc.flops(M),
+                "bytes": 2.0 * M * (pc.Cin + pc.Cout) + 4.0 * 27 * M + 2.0 * pc.Cout * pc.Cin * 9}
+    _lib.call("sgta_dcnv2_fwd_bf16", x.ptr, x.ld, om.ptr, om.ld, pc.wt.data_ptr(), pc.wt.numel() * 2,
+              pc.bias.data_ptr(), out.ptr, out.ld, x.N, x.H, x.W, pc.Cin, pc.Cout, pc.na,
+              pc.tile_log_tw(x.N, x.H, x.W), act, _stream(), meta=meta)
+    return out
+
+
+def stem(img, hm, pc16, out):
+    """relu(bn(conv7x7(img))) + relu(bn(conv7x7(hm))) -> out ViewH bf16 (16 channels).  img / hm: f32 NCHW tensors;
+    pc16: ops.PackedC16 of the two stems (fp32 weights, f32 MFMA: the inputs are fp32 at the boundary)."""
+    assert img.dtype == torch.float32 and hm.dtype == torch.float32 and img.is_contiguous() and hm.is_contiguous()
+    B, _, H, W = img.shape
+    assert out.base.dtype == BF16 and (out.N, out.H, out.W, out.C) == (B, H, W, 16)
+    meta = None
+    if _lib.PROFILE is not None:
+        M = B * H * W
+        meta = {"kernel": "stem_c16_kernel<bf16>", "flops": pc16.flops(M), "exec_flops": pc16.flops(M) * 200.0 / 196.0,
+                "bytes": M * (16.0 + 32.0)}
+    _lib.call("sgta_stem_bf16", img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pc16.wt.data_ptr(),
+              pc16.bias.data_ptr(), out.ptr, out.ld, B, H, W, _stream(), meta=meta)
+    return out
+
+
+def maxpool2(x, out):
+    assert x.base.dtype == BF16 and out.base.dtype == BF16 and out.C == x.C
+    _lib.call("sgta_maxpool2_bf16", x.ptr, x.ld, out.ptr, out.ld, x.N, x.C, x.H, x.W, _stream())
+    return out
+
+
+def pack_up_weight(w):
+    """ConvTranspose2d weight [C,1,k,k] -> f32 [k][k][C] for sgta_upsample_add_bf16."""
+    return w.detach().float()[:, 0].permute(1, 2, 0).contiguous()
+
+
+def upsample_add(x, w_kkc, skip, out, f):
+    sp, lds = (skip.ptr, skip.ld) if skip is not None else (None, 0)
+    _lib.call("sgta_upsample_add_bf16", x.ptr, x.ld, w_kkc.data_ptr(), sp, lds, out.ptr, out.ld, x.N, x.C, x.H, x.W, f,
+              _stream())
+    return out
+
+
+def window_gather(feats, fid, tok, col0=0):
+    B, n = fid.shape
+    assert tok.dtype == torch.float32 and tok.stride(-1) == 1
+    _lib.call("sgta_window_gather_bf16", feats.ptr, feats.ld, fid.data_ptr(), tok.data_ptr(), B, feats.C, feats.H,
+              feats.W, n, tok.stride(0), col0, _stream())
+    return tok
+
+
+def window_scatter(tok, fid, win, feats):
+    B, n = fid.shape
+    assert tok.dtype == torch.float32 and tok.stride(-1) == 1 and tok.shape[-1] == feats.C
+    _lib.call("sgta_window_scatter_bf16", tok.data_ptr(), tok.stride(0), fid.data_ptr(), win.data_ptr(), feats.ptr,
+              feats.ld, B, feats.C, feats.H, feats.W, n, _stream())
+    return feats

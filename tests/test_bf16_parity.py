@@ -1,0 +1,238 @@
+"""GPU (-m gpu): the bf16 data path (BASELINE configs[2]) through the C ABI.
+
+Operator level: each HIP kernel against the same operator evaluated by torch in fp32 ON THE bf16-ROUNDED inputs and
+weights -- so the only differences are accumulation order and the final rounding to bf16 (relative 2^-8): asserted as
+|got - ref| <= 8e-3 |ref| + 2e-3 max|ref|.  Network level: the bf16 engine against the fp32 oracle with the stated
+bf16 tolerance (see test_bf16_network_matches_fp32_oracle).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from util import ARGS, golden_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def bops():
+    from sgtapose_amd import _lib, ops_bf16
+    _lib.load()
+    assert _lib.call("sgta_check_device") == 0
+    return ops_bf16
+
+
+def nhwc(t_nchw):
+    """f32 NCHW (CPU) -> bf16 NHWC on the device."""
+    return t_nchw.permute(0, 2, 3, 1).contiguous().to(BF).to(DEV)
+
+
+def nchw(t_nhwc):
+    return t_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, rtol=8e-3, atol_rel=2e-3):
+    tol = rtol * ref.abs() + atol_rel * float(ref.abs().max())
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), "max err %.4g (ref max %.4g), %d bad" % (
+        float((got - ref).abs().max()), float(ref.abs().max()), int(bad.sum()))
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,ks,stride,act,res", [
+    (2, 32, 64, 9, 13, 1, 1, 0, False), (1, 64, 128, 16, 16, 1, 1, 1, False), (3, 448, 128, 6, 10, 1, 1, 1, False),
+    (2, 16, 16, 20, 36, 3, 1, 1, False), (1, 64, 64, 17, 23, 3, 1, 1, True), (3, 128, 256, 8, 12, 3, 1, 1, True),
+    (2, 16, 32, 16, 24, 3, 2, 1, False), (1, 64, 128, 30, 40, 3, 2, 1, False), (5, 256, 512, 6, 8, 3, 2, 1, False),
+    (4, 512, 512, 15, 20, 3, 1, 1, True), (1, 64, 768, 24, 40, 3, 1, 1, False), (2, 16, 16, 64, 96, 3, 1, 1, False),
+    (2, 64, 32, 12, 70, 3, 1, 0, False), (1, 1280, 512, 15, 20, 1, 1, 1, False),
+])
+def test_conv_bf16(bops, N, cin, cout, H, W, ks, stride, act, res):
+    g = torch.Generator().manual_seed(N * 1000 + cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(BF).float()
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * (1.5 / (cin * ks * ks) ** 0.5))
+    b = torch.randn(cout, generator=g) * 0.2
+    pc = bops.PackedConvBF16(w.to(DEV), b.to(DEV), None, stride=stride)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, cout, Ho, Wo, generator=g).to(BF).float() if res else None
+    ref = F.conv2d(x, pc.w_ref.float().cpu(), b, stride=stride, padding=ks // 2)
+    if res:
+        ref = ref + r
+    if act:
+        ref = F.relu(ref)
+    out = torch.full((N, Ho, Wo, cout), 7.0, dtype=BF, device=DEV)
+    bops.conv(bops.ViewH(nhwc(x)), pc, bops.ViewH(out), act, res=bops.ViewH(nhwc(r)) if res else None)
+    close(nchw(out), ref)
+
+
+def test_conv_bf16_channel_slices_and_fp32_outputs(bops):
+    """Input / output / residual as channel slices of wider buffers (the Root concat buffers), fp32 NHWC output (DCN
+    offsets) and fp32 NCHW output with sigmoid on the first channels (heads)."""
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 14, 22
+    big = torch.randn(N, 96, H, W, generator=g).to(BF).float()
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.1
+    pc = bops.PackedConvBF16(w.to(DEV), b.to(DEV))
+    xin = bops.ViewH(nhwc(big)).slice(32, 32)
+    outbuf = torch.zeros(N, H, W, 160, dtype=BF, device=DEV)
+    bops.conv(xin, pc, bops.ViewH(outbuf).slice(64, 64), 1)
+    ref = F.relu(F.conv2d(big[:, 32:64], pc.w_ref.float().cpu(), b, padding=1))
+    close(nchw(outbuf[..., 64:128]), ref)
+    assert float(outbuf[..., :64].abs().max()) == 0 and float(outbuf[..., 128:].abs().max()) == 0
+    # fp32 NHWC (27 -> 32 channel offset conv)
+    w27 = torch.randn(27, 32, 3, 3, generator=g) * 0.1
+    b27 = torch.randn(27, generator=g) * 0.3
+    pco = bops.PackedConvBF16(w27.to(DEV), b27.to(DEV), cout_pad_to=32)
+    om = torch.full((N, H, W, 32), 3.0, dtype=torch.float32, device=DEV)
+    bops.conv(xin, pco, bops.ViewH(om), 0, out_mode=bops.OUT_F32_NHWC)
+    refo = F.conv2d(big[:, 32:64], pco.w_ref.float().cpu()[:27], b27, padding=1)
+    got = om.cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got[:, :27], refo, atol=2e-3, rtol=1e-3) and float(got[:, 27:].abs().max()) == 0
+    # fp32 NCHW + sigmoid on the first 7 of 11 channels (1x1, 64 -> 11)
+    w11 = torch.randn(11, 64, 1, 1, generator=g) * 0.2
+    b11 = torch.randn(11, generator=g)
+    pch = bops.PackedConvBF16(w11.to(DEV), b11.to(DEV))
+    x64 = torch.randn(N, 64, H, W, generator=g).to(BF).float()
+    o = torch.empty(N, 11, H, W, device=DEV)
+    bops.conv(bops.ViewH(nhwc(x64)), pch, o, 0, out_mode=bops.OUT_F32_NCHW, nsig=7)
+    refh = F.conv2d(x64, pch.w_ref.float().cpu(), b11)
+    refh[:, :7] = torch.sigmoid(refh[:, :7])
+    assert torch.allclose(o.cpu(), refh, atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,off_scale", [(2, 64, 64, 17, 23, 1.5), (1, 128, 128, 15, 20, 4.0),
+                                                      (3, 64, 256, 9, 12, 0.5), (1, 512, 256, 15, 20, 2.0),
+                                                      (2, 256, 64, 30, 40, 8.0)])
+def test_dcn_bf16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
+    """sgta_dcnv2_fwd_bf16 against oracle.dcn_v2_im2col + GEMM on the bf16-rounded x / weights with the SAME fp32
+    offsets and mask logits (border, far-out-of-image and fractional samples)."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(BF).float()
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    om = torch.randn(N, 27, H, W, generator=g) * off_scale
+    pc = bops.PackedDCNBF16(w.to(DEV), b.to(DEV))
+    col = oracle.dcn_v2_im2col(x, om[:, :18], torch.sigmoid(om[:, 18:27]))
+    ref = torch.matmul(pc.w_ref.float().cpu().reshape(cout, cin * 9), col.reshape(N, cin * 9, H * W)).view(N, cout, H, W)
+    ref = F.relu(ref + b.view(1, -1, 1, 1))
+    om32 = torch.zeros(N, H, W, 32, device=DEV)
+    om32[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
+    out = torch.full((N, H, W, cout), 5.0, dtype=BF, device=DEV)
+    bops.dcn_v2(bops.ViewH(nhwc(x)), bops.ViewH(om32), pc, bops.ViewH(out), 1)
+    # the blended sample is rounded to bf16 before the product (the fp32 oracle keeps it in fp32): 2^-9 per sample
+    close(nchw(out), ref, rtol=1e-2, atol_rel=4e-3)
+
+
+def test_elementwise_bf16(bops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 24, 10, 14, generator=g).to(BF).float()
+    out = torch.zeros(3, 5, 7, 40, dtype=BF, device=DEV)
+    bops.maxpool2(bops.ViewH(nhwc(x)), bops.ViewH(out).slice(8, 24))
+    assert torch.equal(nchw(out[..., 8:32]), F.max_pool2d(x, 2))
+    for f in (2, 4):
+        w = torch.randn(24, 1, 2 * f, 2 * f, generator=g)
+        skip = torch.randn(3, 24, 10 * f, 14 * f, generator=g).to(BF).float()
+        ref = F.conv_transpose2d(x, w, stride=f, padding=f // 2, groups=24) + skip
+        o = torch.empty(3, 10 * f, 14 * f, 24, dtype=BF, device=DEV)
+        bops.upsample_add(bops.ViewH(nhwc(x)), bops.pack_up_weight(w.to(DEV)), bops.ViewH(nhwc(skip)), bops.ViewH(o), f)
+        close(nchw(o), ref, rtol=8e-3, atol_rel=2e-3)
+    # window gather / ordered scatter
+    B, C, H, W, n = 3, 24, 10, 14, 20
+    fid = torch.randint(0, H * W, (B, n), generator=g)
+    fid[0, 5] = fid[0, 2]                                  # duplicate: the LAST token wins
+    win = torch.ones(B, n, dtype=torch.uint8)              # winners = tokens with no later duplicate (sgta_window_index)
+    for b in range(B):
+        for t_ in range(n):
+            win[b, t_] = int(not bool((fid[b, t_ + 1:] == fid[b, t_]).any()))
+    assert win[0, 2] == 0
+    feats = bops.ViewH(nhwc(x))
+    tok = torch.zeros(B * n, 32, device=DEV)
+    bops.window_gather(feats, fid.to(DEV), tok, col0=8)
+    ref = torch.gather(x.reshape(B, C, -1), 2, fid.view(B, 1, n).expand(B, C, n)).permute(0, 2, 1).reshape(B * n, C)
+    assert torch.equal(tok[:, 8:].cpu(), ref) and float(tok[:, :8].abs().max()) == 0
+    new = torch.randn(B * n, C, generator=g)
+    bops.window_scatter(new.to(DEV), fid.to(DEV), win.to(DEV), feats)
+    want = x.reshape(B, C, -1).clone()
+    for b in range(B):
+        for t in range(n):
+            want[b, :, fid[b, t]] = new[b * n + t].to(BF).float()
+    assert torch.equal(nchw(feats.base).reshape(B, C, -1), want)
+
+
+def test_stem_bf16(bops):
+    from sgtapose_amd.ops import PackedC16
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 2, 24, 40
+    img = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    hm = torch.rand(B, 1, H, W, generator=g)
+    wi, wh = torch.randn(16, 3, 7, 7, generator=g) * 0.1, torch.randn(16, 1, 7, 7, generator=g) * 0.15
+    bn = lambda: (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1,      # noqa: E731
+                  torch.randn(16, generator=g) * 0.1, torch.rand(16, generator=g) + 0.5)
+    bi, bh = bn(), bn()
+    pc = PackedC16(wi.to(DEV), tuple(t.to(DEV) for t in bi), wh.to(DEV), tuple(t.to(DEV) for t in bh))
+    out = torch.empty(B, H, W, 16, dtype=BF, device=DEV)
+    bops.stem(img.to(DEV), hm.to(DEV), pc, bops.ViewH(out))
+    ref = (F.relu(F.batch_norm(F.conv2d(img, wi, padding=3), bi[2], bi[3], bi[0], bi[1], False, 0.0, 1e-5)) +
+           F.relu(F.batch_norm(F.conv2d(hm, wh, padding=3), bh[2], bh[3], bh[0], bh[1], False, 0.0, 1e-5)))
+    close(nchw(out), ref, rtol=5e-3, atol_rel=1e-3)
+
+
+# ---- network level ---------------------------------------------------------------------------------------------------
+BF16_LOGIT_TOL = 6e-2      # max |logit_bf16 - logit_fp32 oracle| asserted for hm / reg / tracking (measured ~2e-2)
+BF16_LOGIT_MEAN_TOL = 8e-3
+
+
+def _bf16_model(peaked=False):
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
+    m.load_state_dict(golden_state_dict(0, peaked=peaked), strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "bf16"
+    return m
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(2, 128, 160, 11), (1, 480, 640, 321), (3, 96, 224, 13)])
+def test_bf16_network_matches_fp32_oracle(B, H, W, seed):
+    """The whole bf16 engine against the fp32 CPU oracle: bf16 feature maps / weights (8 significant bits) through ~60
+    layers.  Stated tolerance: max |logit error| <= 6e-2 and mean <= 8e-3 on all three heads (fp32 path: 1e-3)."""
+    from sgtapose_amd.engine_bf16 import EngineBF16
+    from sgtapose_amd.synthetic import make_inputs
+    m = _bf16_model()
+    assert isinstance(m.engine(), EngineBF16)
+    inp = make_inputs(B, H, W, seed=seed)
+    out = m(*[inp[k].to(DEV) for k in ARGS])[-1]
+    ref = oracle.plan_a_window_forward(golden_state_dict(0), *[inp[k] for k in ARGS])
+    for k in ("hm", "reg", "tracking"):
+        assert out[k].dtype == torch.float32 and out[k].shape == ref[k].shape
+        d = (out[k].cpu() - ref[k]).abs()
+        print("bf16 vs fp32 oracle %-8s max %.4f mean %.5f (ref std %.3f)" % (k, float(d.max()), float(d.mean()), float(ref[k].std())))
+        assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
+
+
+def test_bf16_detector_keypoints_on_peaked_weights():
+    """network -> sigmoid -> decode in bf16 with the peaked weight set.  That set multiplies the 'hm' logits by 30, so the
+    bf16 logit noise (~3e-2) becomes ~1 logit and the random-init peak structure is NOT stable under it: the test
+    reports the heat-map error and asserts only what bf16 can promise there -- saturated reference key-points (score >
+    0.9) reappear within one pixel in at least half of the cases, and whatever both paths find at the same integer pixel
+    agrees to 0.1 px after the offset head.  (Integer-peak identity is asserted where it is meaningful: on peaked MAPS fed
+    to the decode, test_hip_parity.py, and for the fp32 path end to end.)"""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _bf16_model(peaked=True)
+    inp = make_inputs(4, 128, 160, seed=11)
+    out, dets = BatchedDetector(m).process_device(*[inp[k].to(DEV) for k in ARGS])
+    ref_out, ref_dets = oracle.process_reference(golden_state_dict(0, peaked=True), *[inp[k] for k in ARGS])
+    hm_err = float((out["hm"].cpu() - ref_out["hm"]).abs().max())
+    clear = ref_dets["scores"] > 0.9
+    xs, ys = dets["xs"].cpu().numpy(), dets["ys"].cpu().numpy()
+    near = (np.abs(xs - ref_dets["xs"]) <= 1) & (np.abs(ys - ref_dets["ys"]) <= 1) & (dets["scores"].cpu().numpy() > 0)
+    same = (xs == ref_dets["xs"]) & (ys == ref_dets["ys"]) & (ref_dets["scores"] > 0) & (dets["scores"].cpu().numpy() > 0)
+    print("bf16 peaked: hm max abs %.4f; saturated reference key-points %d, within 1 px %d; identical integer peaks %d" % (
+        hm_err, int(clear.sum()), int((near & clear).sum()), int(same.sum())))
+    assert int(clear.sum()) >= 2 and int((near & clear).sum()) * 2 >= int(clear.sum())
+    if same.any():
+        l2 = np.sqrt(((dets["cts_wreg"].cpu().numpy() - ref_dets["cts_wreg"])[same] ** 2).sum(1)).max()
+        assert l2 < 0.1, l2
