@@ -121,7 +121,11 @@ int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* wt, const fl
  *           wt [144][16] with k = c*9 + ky*3 + kx (BN scale folded), bias [16]
  *   mode 1: fused stems = relu(bn(conv7x7(x = image [B,3,H,W]))) + relu(bn(conv7x7(x2 = heat-map [B,1,H,W])))
  *           (dla.py:259-270, :324-328); wt = [148][16] image matrix (k = ch*49 + ky*7 + kx, row 147 zero)
- *           followed by [52][16] heat-map matrix (k = ky*7 + kx, rows 49..51 zero), bias [32]. */
+ *           followed by [52][16] heat-map matrix (k = ky*7 + kx, rows 49..51 zero), bias [32].
+ *   sequence mode (the two stems are separate conv+BN+ReLU whose outputs are only summed,
+ *   dla.py:260-270, :325-328, so the image stem of frame t is computed once and reused when t becomes the previous frame):
+ *   mode 2: image stem only, y = relu(bn(conv7x7(x = image)))                 (x2 ignored; weights / bias as mode 1)
+ *   mode 3: y = x (the CACHED image stem [B,16,H,W]) + relu(bn(conv7x7(x2 = heat-map))) */
 int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt,
                       const float* bias, float* y, long y_bs, int B, int H, int W, int mode,
                       sgta_stream_t stream);
@@ -277,6 +281,15 @@ int sgta_post_process(const float* scores, const long long* cts, const float* ct
                       const float* tracking, const float* trans_inv, float out_thresh, unsigned char* valid,
                       float* ct, float* ct_wreg, float* reg, float* trk, double* final_kps, int B, int K,
                       sgta_stream_t stream);
+
+/* SGTADetector.pre_process (sgtapose/lib/sgta_detector.py:368-399, normalize_img :401-402) for a batch of raw frames of
+ * one size: cv2.warpAffine(image, trans_input, (Wo, Ho), INTER_LINEAR, constant border 0) + (img / 255 - mean) / std in
+ * float32 + HWC -> CHW.  images u8 [B,Hr,Wr,3]; inv_trans f64 [B,2,3] = the INVERSE of meta['trans_input'] (computed by
+ * the caller in double exactly as OpenCV's warpAffine does); mean / stdv f32 [3]; out f32 [B,3,Ho,Wo].  The warp restates
+ * OpenCV's published 8-bit algorithm (1/32-pixel fixed-point coordinates, 15-bit weights); OpenCV is absent from the
+ * image, so it is unpinned against the library and bit-exact against oracle/prepost.py. */
+int sgta_pre_process(const unsigned char* images, const double* inv_trans, const float* mean, const float* stdv,
+                     float* out, int B, int Hr, int Wr, int Ho, int Wo, sgta_stream_t stream);
 
 /* ---- bf16 data path (BASELINE configs[2]: bf16 feature maps / weights, fp32 accumulate / softmax / LayerNorm / decode) ----
  * Feature maps are bf16 CHANNELS-LAST [N,H,W,ld] (``ld`` = channels of the underlying buffer, so a tensor may be a

@@ -27,5 +27,6 @@ from .temporal import (topk_index, window_coords, window_gather, mhca_forward,  
                        encoder_layer_forward, encoder_forward, substitute_tokens)
 from .decode import (gaussian_filter_f32, peaks_from_maps, peaks_info, dream_decode,  # noqa: F401
                      soft_argmax_pavlo)
-from .forward import plan_a_window_forward, plan_a_window_three_forward, process_reference   # noqa: F401
+from .forward import (plan_a_window_forward, plan_a_window_three_forward, plan_a_window_seq_forward,   # noqa: F401
+                      seq_keys_from_three, process_reference)
 from . import prepost                                                   # noqa: F401  (section 8f rank 1)

@@ -116,6 +116,56 @@ def plan_a_window_three_forward(sd, x, ppre_img, pre_img, ppre_hm, pre_hm, repro
         return {h: head_forward(y[-1], sd, h) for h in HEADS_THREE}
 
 
+# ---- T-frame generalisation (BASELINE configs[4]; no reference beyond T = 3) ------------------------------------------------
+def seq_keys_from_three(sd):
+    """state_dict of DLA_PlanAWindow_Three -> the key names of the T = 3 instance of the generalised model."""
+    out = {}
+    for k, v in sd.items():
+        k2 = k.replace("pprev_transformer.", "frame_transformer.0.") if k.startswith("pprev_transformer.") else \
+            (k.replace("prev_transformer.", "frame_transformer.1.") if k.startswith("prev_transformer.") else k)
+        out[k2] = v
+    return out
+
+
+def plan_a_window_seq_forward(sd, x, pre_imgs, pre_hms, repro_hm, pre_hm_clss, repro_hm_cls, ks=KS_DEFAULT,
+                              use_pos=True, legacy_slip=False):
+    """DLA_PlanAWindow_Three.imgpre2feats (dla.py:1400-1456) generalised to T - 1 = len(pre_imgs) previous frames
+    (oldest first): one encoder stream per previous frame against the same current-frame queries at levels 0-2
+    (``frame_transformer.k.i``), outputs concatenated with the current tokens -> cat_layer (T*C -> 2T*C -> C); levels 3-5:
+    cat_layer on every pixel of cat[frame_0 .. frame_{T-2}, cur].  ``legacy_slip`` (T = 3 only) = the reference's
+    ``ppre_f = pre_feats`` at levels 3-5 (dla.py:1435): with it and ``seq_keys_from_three`` this IS
+    plan_a_window_three_forward, which is pinned against the reference.  -> {'hm','reg','wh','tracking'} logits."""
+    n_prev = len(pre_imgs)
+    assert n_prev >= 2 and len(pre_hms) == n_prev and len(pre_hm_clss) == n_prev and not (legacy_slip and n_prev != 2)
+    with torch.no_grad():
+        xs_prev = [dla34_backbone(pre_imgs[k], pre_hms[k], sd) for k in range(n_prev)]
+        x_cur = dla34_backbone(x, repro_hm, sd)
+        idx_prev = [topk_index(c) for c in pre_hm_clss]
+        cur_idx = topk_index(repro_hm_cls)
+        out = list(x_cur)
+        for i in range(6):
+            cur_f = x_cur[i]
+            H, W = cur_f.shape[2:]
+            if i <= 2:
+                cur_fid = window_coords(cur_idx, SCALE_LIST[i], ks[i], H, W)
+                qry = window_gather(cur_f, cur_fid)
+                toks = []
+                for k in range(n_prev):
+                    key = window_gather(xs_prev[k][i], window_coords(idx_prev[k], SCALE_LIST[i], ks[i], H, W))
+                    toks.append(encoder_forward(qry, key, key, sd, "frame_transformer.%d.%d" % (k, i), use_pos=use_pos))
+                out[i] = substitute_tokens(torch.cat(toks, dim=-1), cur_f, cur_fid, sd, "cat_layer.%d" % i)
+            else:
+                p = "cat_layer.%d" % i
+                prev = [xs_prev[-1][i]] * n_prev if legacy_slip else [xs_prev[k][i] for k in range(n_prev)]
+                z = torch.cat([f.permute(0, 2, 3, 1) for f in prev] + [cur_f.permute(0, 2, 3, 1)], dim=-1).contiguous()
+                z = F.linear(F.relu(F.linear(z, sd[p + ".0.weight"], sd[p + ".0.bias"])), sd[p + ".2.weight"], sd[p + ".2.bias"])
+                out[i] = z.permute(0, 3, 1, 2).contiguous()
+        ups = dla_up_forward(out, sd)
+        y = [ups[0].clone(), ups[1].clone(), ups[2].clone()]
+        ida_up_forward(y, 0, 3, sd, "ida_up")
+        return {h: head_forward(y[-1], sd, h) for h in HEADS_THREE}
+
+
 def process_reference(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, K=7, **kw):
     """SGTADetector.process for phase PlanA_win: forward, in-place sigmoid on 'hm', decode.
     Returns (output dict with post-sigmoid hm, dets dict of numpy arrays)."""

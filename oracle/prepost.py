@@ -180,3 +180,52 @@ def get_final_kps(dets, num_classes):
             continue
         detected_kps[i - 1] = [x_list[-1][1], y_list[-1][1]]
     return detected_kps
+
+
+# ---- SGTADetector.pre_process: cv2.warpAffine + normalize_img (sgta_detector.py:368-402) ------------------------------------
+def invert_affine(m):
+    """cv2.warpAffine's inversion of M (OpenCV imgproc/imgwarp.cpp, double)."""
+    m = np.asarray(m, np.float64)
+    d = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22 = m[1, 1] * d, m[0, 0] * d
+    i00, i01, i10, i11 = a11, m[0, 1] * -d, m[1, 0] * -d, a22
+    return np.array([[i00, i01, -i00 * m[0, 2] - i01 * m[1, 2]], [i10, i11, -i10 * m[0, 2] - i11 * m[1, 2]]], np.float64)
+
+
+def warp_affine_u8(img, M, dsize):
+    """cv2.warpAffine(img u8 [H,W,C], M, (w, h), flags=INTER_LINEAR), constant border 0, restated from OpenCV's published
+    8-bit algorithm (WarpAffineInvoker + remapBilinear, imgwarp.cpp): AB_BITS = 10, INTER_BITS = 5, weights scaled by 2^15.
+    UNPINNED (OpenCV is not in the image); a float bilinear warp agrees to the 1/32-pixel coordinate quantisation."""
+    w, h = dsize
+    Hr, Wr, C = img.shape
+    iM = invert_affine(M)
+    xs = np.arange(w, dtype=np.float64)
+    ys = np.arange(h, dtype=np.float64)
+    adelta = np.rint(iM[0, 0] * xs * 1024.0).astype(np.int64)
+    bdelta = np.rint(iM[1, 0] * xs * 1024.0).astype(np.int64)
+    X0 = np.rint((iM[0, 1] * ys + iM[0, 2]) * 1024.0).astype(np.int64) + 16
+    Y0 = np.rint((iM[1, 1] * ys + iM[1, 2]) * 1024.0).astype(np.int64) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    out = np.zeros((h, w, C), np.int64)
+    src = img.astype(np.int64)
+    for dy, dx, wgt in ((0, 0, (32 - fx) * (32 - fy) * 32), (0, 1, fx * (32 - fy) * 32),
+                        (1, 0, (32 - fx) * fy * 32), (1, 1, fx * fy * 32)):
+        yy, xx = sy + dy, sx + dx
+        ok = (yy >= 0) & (yy < Hr) & (xx >= 0) & (xx < Wr)
+        v = src[np.clip(yy, 0, Hr - 1), np.clip(xx, 0, Wr - 1)]
+        out += np.where(ok[..., None], v, 0) * wgt[..., None]
+    return ((out + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def pre_process(image_u8, trans_input, inp_w, inp_h, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """sgta_detector.py:381-386: warp, ((img / 255. - mean) / std).float32 as torch evaluates it, HWC -> [1,3,h,w]."""
+    import torch
+    warped = torch.from_numpy(warp_affine_u8(image_u8, trans_input, (inp_w, inp_h)))
+    mean_t = torch.tensor(mean, dtype=torch.float32).reshape(1, 1, 3)
+    std_t = torch.tensor(std, dtype=torch.float32).reshape(1, 1, 3)
+    x = ((warped / 255. - mean_t) / std_t).type(torch.float32)
+    return x.permute(2, 0, 1).reshape(1, 3, inp_h, inp_w)

@@ -207,6 +207,7 @@ extern "C" int sgta_conv1x1_f32(const float* x, long x_bs, const float* wt, cons
   if (act == 1 && res_mode == 0) return launch_c1<1, 0>(a, st);
   if (act == 0 && res_mode == 0) return launch_c1<0, 0>(a, st);
   if (act == 1 && res_mode == 1) return launch_c1<1, 1>(a, st);
+  if (act == 0 && res_mode == 1) return launch_c1<0, 1>(a, st);     // partial sums of the T-frame full-map cat-MLP
   if (act == 1 && res_mode == 2) return launch_c1<1, 2>(a, st);
   if (act == 2 && res_mode == 0) return launch_c1<2, 0>(a, st);
   return SGTA_EBADARG;

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
 // slots: 50 MFMAs per 16 pixels instead of 98.
 // NHWC_BF16: the bf16 data path's stem -- same arithmetic (fp32 inputs, f32 MFMA), output rounded to bf16 and written
 // channels-last [B,H,W,ldy] (a lane holds 4 consecutive output channels of its pixel: one 8-byte store; a.y_bs = ldy)
-template <bool NHWC_BF16>
+// MODE 0: both stems fused (default).  Sequence mode (the image stem of frame t, computed when
+// t is the current frame, is reused when t is the previous frame): MODE 1 = image stem only, y = relu(bn(conv7x7(img)));
+// MODE 2 = heat-map stem only plus the cached image stem, y = a.x (cached [B,16,H,W]) + relu(bn(conv7x7(hm))).
+template <bool NHWC_BF16, int MODE = 0>
 __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
   constexpr int KS = 7, TH = 8, TW = 32, KK = 49, P = 3;
   constexpr int WH = TH + KS - 1, WW = TW + KS - 1;
@@ -152,8 +155,15 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
     const int gy = ty0 - P + r / WW, gx = tx0 - P + r % WW;
     const bool ok = e < NCH * WSZ0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     const int chc = ok ? ch : 0;
-    const float* src = chc == 3 ? a.x2 + (long)b * a.x2_bs : a.x + (long)b * a.x_bs + (long)chc * HW;
-    const float v = src[ok ? gy * W + gx : 0];
+    float v = 0.0f;
+    if (MODE == 0) {
+      const float* src = chc == 3 ? a.x2 + (long)b * a.x2_bs : a.x + (long)b * a.x_bs + (long)chc * HW;
+      v = src[ok ? gy * W + gx : 0];
+    } else if (MODE == 1) {                          // image planes only
+      if (ch < 3) v = (a.x + (long)b * a.x_bs + (long)chc * HW)[ok ? gy * W + gx : 0];
+    } else {                                         // heat-map plane only
+      if (ch == 3) v = (a.x2 + (long)b * a.x2_bs)[ok ? gy * W + gx : 0];
+    }
     pv[t] = ok ? v : 0.0f;
   }
   constexpr int A_PER = ((NKI + NKH) * 16 / 4 + 255) / 256;
@@ -201,14 +211,17 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[s2][n] = f32x4{0, 0, 0, 0};
+  if (MODE != 2) {
 #pragma unroll
-  for (int s2 = 0; s2 < SI; ++s2) {
-    const float av = As[(4 * s2 + g) * 16 + c16];
-    const float* wrow = win + offtab[4 * s2 + g];
+    for (int s2 = 0; s2 < SI; ++s2) {
+      const float av = As[(4 * s2 + g) * 16 + c16];
+      const float* wrow = win + offtab[4 * s2 + g];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-      acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[pix[n]], acc[0][n], 0, 0, 0);
+      for (int n = 0; n < 4; ++n)
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[pix[n]], acc[0][n], 0, 0, 0);
+    }
   }
+  if (MODE != 1)
 #pragma unroll
   for (int s2 = 0; s2 < SH; ++s2) {
     const float av = As[(NKI + 4 * s2 + g) * 16 + c16];
@@ -237,7 +250,12 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = 4 * g + r;
-      yb[(long)co * HW] = fmaxf(acc[0][n][r] + a.bias[co], 0.0f) + fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
+      if (MODE == 0)
+        yb[(long)co * HW] = fmaxf(acc[0][n][r] + a.bias[co], 0.0f) + fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
+      else if (MODE == 1)
+        yb[(long)co * HW] = fmaxf(acc[0][n][r] + a.bias[co], 0.0f);
+      else                                           // same operand order as the fused form: image stem + heat-map stem
+        yb[(long)co * HW] = (a.x + (long)b * a.x_bs + (long)co * HW)[y * W + x] + fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
     }
   }
 }
@@ -253,6 +271,10 @@ extern "C" int sgta_conv_c16_f32(const float* x, long x_bs, const float* x2, lon
     hipLaunchKernelGGL((conv_c16_kernel<3, 4, false>), dim3(grid), dim3(256), 0, st, a);
   else if (mode == 1 && x2)                        // fused stems: 7x7 (3 -> 16) and (1 -> 16)
     hipLaunchKernelGGL(stem_c16_kernel<false>, dim3(grid), dim3(256), 0, st, a);
+  else if (mode == 2)                              // sequence mode: image stem only  (x = image, x2 unused)
+    hipLaunchKernelGGL((stem_c16_kernel<false, 1>), dim3(grid), dim3(256), 0, st, a);
+  else if (mode == 3 && x2)                        // sequence mode: x = cached image stem [B,16,H,W], x2 = prior map
+    hipLaunchKernelGGL((stem_c16_kernel<false, 2>), dim3(grid), dim3(256), 0, st, a);
   else
     return SGTA_EBADARG;
   SGTA_LAUNCH_CHECK();

@@ -101,3 +101,55 @@ extern "C" int sgta_post_process(const float* scores, const long long* cts, cons
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
+
+// ---- SGTADetector.pre_process (sgta_detector.py:368-399): cv2.warpAffine(image, trans_input, (inp_w, inp_h), INTER_LINEAR,
+// border constant 0) followed by normalize_img ((img / 255 - mean) / std in float32, :401-402) and HWC -> CHW.
+// The warp restates OpenCV's published 8-bit algorithm (imgwarp.cpp WarpAffineInvoker + remapBilinear): the inverse
+// matrix is applied in double, source coordinates are fixed-point with 10 fractional bits (rounded to nearest, ties to
+// even) truncated to 1/32 pixel, the four weights are (32-fx)(32-fy)*32 ... (sum 2^15) and the result is
+// (sum + 2^14) >> 15.  OpenCV is not in the image: UNPINNED against the library, bit-exact against oracle/prepost.py.
+__global__ __launch_bounds__(256) void pre_process_kernel(const unsigned char* __restrict__ img, const double* __restrict__ inv_m,
+                                                          const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                          float* __restrict__ out, int Hr, int Wr, int Ho, int Wo, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % Wo);
+    long t = i / Wo;
+    const int y = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const double* m = inv_m + b * 6;
+    const int adelta = __double2int_rn(__dmul_rn(__dmul_rn(m[0], (double)x), 1024.0));
+    const int bdelta = __double2int_rn(__dmul_rn(__dmul_rn(m[3], (double)x), 1024.0));
+    const int X0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(m[1], (double)y), m[2]), 1024.0)) + 16;
+    const int Y0 = __double2int_rn(__dmul_rn(__dadd_rn(__dmul_rn(m[4], (double)y), m[5]), 1024.0)) + 16;
+    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    int sx = X >> 5, sy = Y >> 5;
+    sx = min(max(sx, -32768), 32767);             // saturate_cast<short>
+    sy = min(max(sy, -32768), 32767);
+    const int fx = X & 31, fy = Y & 31;
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const unsigned char* src = img + (long)b * Hr * Wr * 3;
+    const bool x0 = (unsigned)sx < (unsigned)Wr, x1 = (unsigned)(sx + 1) < (unsigned)Wr;
+    const bool y0 = (unsigned)sy < (unsigned)Hr, y1 = (unsigned)(sy + 1) < (unsigned)Hr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int s = 0;
+      if (y0 && x0) s += src[((long)sy * Wr + sx) * 3 + c] * w00;
+      if (y0 && x1) s += src[((long)sy * Wr + sx + 1) * 3 + c] * w01;
+      if (y1 && x0) s += src[((long)(sy + 1) * Wr + sx) * 3 + c] * w10;
+      if (y1 && x1) s += src[((long)(sy + 1) * Wr + sx + 1) * 3 + c] * w11;
+      const int v = (s + (1 << 14)) >> 15;
+      const float q = __fdiv_rn((float)v, 255.0f);
+      out[(((long)b * 3 + c) * Ho + y) * Wo + x] = __fdiv_rn(__fsub_rn(q, mean[c]), stdv[c]);
+    }
+  }
+}
+
+extern "C" int sgta_pre_process(const unsigned char* images, const double* inv_trans, const float* mean, const float* stdv,
+                                float* out, int B, int Hr, int Wr, int Ho, int Wo, hipStream_t st) {
+  if (!images || !inv_trans || !mean || !stdv || !out || B <= 0 || Hr <= 0 || Wr <= 0 || Ho <= 0 || Wo <= 0) return SGTA_EBADARG;
+  const long total = (long)B * Ho * Wo;
+  const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(pre_process_kernel, dim3(grid), dim3(256), 0, st, images, inv_trans, mean, stdv, out, Hr, Wr, Ho, Wo, total);
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}

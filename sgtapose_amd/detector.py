@@ -77,3 +77,47 @@ class BatchedDetector:
     def keypoints(dets):
         """[B,K,3] float32 (x + reg_x, y + reg_y, score) -- the tensor that is all-gathered across ranks."""
         return dets["kp"]                  # written by the decode kernel (sgta_peaks_decode_kp): no glue kernels
+
+
+class SequenceDetector(BatchedDetector):
+    """Stateful video mode: frame t's image stem ``relu(bn(conv7x7(img_t)))`` is computed
+    once, when t is the current frame, and reused at step t + 1 where t is the previous frame -- exact up to nothing: the
+    two stems are separate conv+BN+ReLU branches whose outputs are only summed (dla.py:260-270, :325-328); nothing
+    deeper can be reused because the summed heat-map stem differs (repro_hm vs pre_hm, dla.py:1506-1507).  Saves one 7x7
+    image conv and one image read per frame pair.  fp32 engine only."""
+
+    def __init__(self, model, opt=None):
+        super().__init__(model, opt)
+        self._stem = [None, None]              # ping-pong buffers: previous frame's / current frame's image stem
+        self._have_prev = False
+
+    def reset(self):
+        self._have_prev = False
+
+    @torch.no_grad()
+    def step_device(self, image, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, pre_image=None, static=False):
+        """One video step.  ``pre_image`` is only needed for the first step (or after ``reset``); afterwards the previous
+        frame is the ``image`` of the previous call.  Returns (output, dets) like ``process_device``."""
+        from .engine import CachedStem
+        eng = self.model.engine()
+        if getattr(eng, "dtype", "f32") != "f32":
+            raise ValueError("sequence mode is built for the fp32 engine")
+        B, _, H, W = image.shape
+        shape = (B, 16, H, W)
+        for k in (0, 1):
+            if self._stem[k] is None or tuple(self._stem[k].shape) != shape:
+                self._stem[k] = torch.empty(shape, dtype=torch.float32, device=image.device)
+                self._have_prev = False
+        if not self._have_prev:
+            if pre_image is None:
+                raise ValueError("the first step of a sequence needs pre_image")
+            eng.image_stem(pre_image, self._stem[0])
+        eng.image_stem(image, self._stem[1])
+        out = eng.forward(CachedStem(self._stem[1]), CachedStem(self._stem[0]), pre_hm, repro_hm, pre_hm_cls, repro_hm_cls,
+                          hm_act=ops.ACT_SIGMOID, static=static)
+        self._stem.reverse()                   # the current frame's stem is the next step's previous-frame stem
+        self._have_prev = True
+        hm = out["hm"]
+        ws = (eng.buf("dec_tmp", tuple(hm.shape)), eng.buf("dec_filt", tuple(hm.shape)))
+        bufs = ops.decode_buffers(hm.shape[0], self.K, hm.device, "reg" in out, alloc=eng.buf) if static else None
+        return out, dream_generic_decode(out, K=self.K, opt=self.opt, ws=ws, out=bufs)

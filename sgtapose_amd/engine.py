@@ -26,6 +26,25 @@ def _bn_tuple(bn):
             bn.running_var.detach().float())
 
 
+class CachedStem:
+    """Stand-in for a frame's image in sequence mode: ``stem`` = relu(bn(conv7x7(image))) [B,16,H,W], computed when the
+    frame was the current one (exact because the two stems are only summed, dla.py:325-328)."""
+
+    def __init__(self, stem):
+        self.stem = stem
+        self.shape = (stem.shape[0], 3, stem.shape[2], stem.shape[3])
+
+    def contiguous(self):
+        return self
+
+    def float(self):
+        return self
+
+    @property
+    def device(self):
+        return self.stem.device
+
+
 class Engine:
     def __init__(self, model):
         p = next(model.parameters())
@@ -178,6 +197,13 @@ class Engine:
         self._tree_l1(node.tree1, name + ".tree1", x, t1, cat1, bottom=bottom)
         return self._tree_l1(inner, name + ".tree2", t1, out, cat2)
 
+    def image_stem(self, img, out=None):
+        """relu(bn(conv7x7(img))) alone -> [B,16,H,W] (sequence mode: cached for the next step)."""
+        B, _, H, W = img.shape
+        out = torch.empty((B, 16, H, W), dtype=torch.float32, device=self.dev) if out is None else out
+        ops.conv_c16(img.contiguous().float(), None, self.P["stem.c16"], out, mode=2)
+        return out
+
     def backbone(self, x, pre_img, pre_hm, repro_hm, after_level=None):
         """Both frames as one batch of 2B (previous first).  Returns the six level Views [2B, C_i, ...].
         ``after_level(i, view)`` is called as soon as level i's kernels are enqueued."""
@@ -192,7 +218,9 @@ class Engine:
         s = self.buf("stem", (N, 16, H, W))
         for half, (img, hm) in enumerate(frames):
             sl = slice(half * B, (half + 1) * B)
-            if self.use_c16:                       # both 7x7 stems + BN + ReLU + sum in one kernel
+            if isinstance(img, CachedStem):        # sequence mode: the image stem of this frame already exists
+                ops.conv_c16(img.stem, hm, P["stem.c16"], View(s[sl]), mode=3)
+            elif self.use_c16:                     # both 7x7 stems + BN + ReLU + sum in one kernel
                 ops.conv_c16(img, hm, P["stem.c16"], View(s[sl]))
             else:
                 t = self.buf("stem_hm", (N, 16, H, W))

@@ -10,10 +10,11 @@ from types import SimpleNamespace
 
 import torch
 
-from .networks.dla import DLAPlanAWindowL3New, DLAPlanAWindowThree
+from .networks.dla import DLAPlanAWindowL3New, DLAPlanAWindowSeq, DLAPlanAWindowThree
 
 _network_factory = {"dlapawdl3new": DLAPlanAWindowL3New,          # the live model (sgtapose/lib/model/model.py:19)
-                    "dlapawd3": DLAPlanAWindowThree}              # three-frame variant (model.py:18)
+                    "dlapawd3": DLAPlanAWindowThree,              # three-frame variant (model.py:18)
+                    "dlapawdT": DLAPlanAWindowSeq}                # this build's T-frame generalisation (opt.seq_len, default 4)
 
 DEFAULT_HEADS = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}        # opts_parallel.py:392-395
 
@@ -39,7 +40,7 @@ def create_model(arch, head, head_conv, opt=None):
     num_layers = int(arch[arch.find("_") + 1:]) if "_" in arch else 0
     name = arch[:arch.find("_")] if "_" in arch else arch
     if name not in _network_factory:
-        raise KeyError("architecture %r is outside the hot path; supported: dlapawdl3new_34, dlapawd3_34" % arch)
+        raise KeyError("architecture %r is outside the hot path; supported: dlapawdl3new_34, dlapawd3_34, dlapawdT_34" % arch)
     return _network_factory[name](num_layers, heads=head, head_convs=head_conv, opt=opt or default_opt())
 
 

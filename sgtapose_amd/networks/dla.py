@@ -353,3 +353,55 @@ class DLAPlanAWindowThree(nn.Module):
     def _apply(self, fn, *a, **k):
         self._engine = None
         return super()._apply(fn, *a, **k)
+
+
+class DLAPlanAWindowSeq(DLAPlanAWindowThree):
+    """``DLA_PlanAWindow_Three`` generalised to a temporal window of T = ``opt.seq_len`` frames (T - 1 previous frames +
+    the current one; BASELINE configs[4] asks for T = 4, the reference stops at T = 3: SURVEY.md section 8f rank 2).
+    One attention stream per previous frame against the same current-frame queries at levels 0-2
+    (``frame_transformer.k.i``, k = 0 the OLDEST frame), their outputs concatenated with the current tokens before
+    ``cat_layer`` of width T*C -> 2T*C -> C; at levels 3-5 cat_layer runs on every pixel of cat[frame_0 .. frame_{T-2}, cur].
+    ``opt.legacy_slip`` reproduces the reference's T = 3 behaviour (``ppre_f = pre_feats`` at levels 3-5, dla.py:1435) so
+    that the T = 3 instance is checked against the reference's own outputs (keys: pprev_transformer -> frame_transformer.0,
+    prev_transformer -> frame_transformer.1)."""
+
+    def __init__(self, num_layers, heads, head_convs, opt):
+        T = int(getattr(opt, "seq_len", 4))
+        if T < 3:
+            raise ValueError("seq_len must be >= 3 (the two-frame model is dlapawdl3new_34)")
+        super().__init__(num_layers, heads, head_convs, opt)
+        self.n_frames = T
+        self.legacy_slip = bool(getattr(opt, "legacy_slip", False))
+        if self.legacy_slip and T != 3:
+            raise ValueError("legacy_slip only exists for seq_len 3")
+        ncls = opt.num_classes
+        for name in ("pprev_transformer", "prev_transformer"):
+            if hasattr(self, name):
+                delattr(self, name)
+        self.shared_ca = False
+        self.frame_transformer = nn.ModuleList([
+            nn.ModuleList([Encoder(EncoderLayer(16 * 2 ** i, 4 * 2 ** i,
+                                                ncls * self.K_list[i] * (1 + 2 * (self.kernel_list[i] // 2)) ** 2), 3)
+                           for i in range(3)]) for _ in range(T - 1)])
+        self.cat_layer = nn.ModuleList([
+            nn.Sequential(nn.Linear(16 * 2 ** i * T, 32 * 2 ** i * T), nn.ReLU(), nn.Linear(32 * 2 ** i * T, 16 * 2 ** i))
+            for i in range(6)])
+        # levels 3-5 have no window size of their own in the three-frame class: same defaults as the two-frame model
+        self.kernel_list = self.kernel_list + [1, 1, 1]
+        self.scale_list = (4, 2, 1, 1 / 2, 1 / 4, 1 / 8)
+
+    def forward(self, x, pre_imgs=None, pre_hms=None, repro_hm=None, pre_hm_clss=None, repro_hm_cls=None):
+        """x [B,3,H,W]; pre_imgs / pre_hms / pre_hm_clss: sequences of T-1 tensors, OLDEST first; -> [{'hm','reg','wh','tracking'}]."""
+        n = self.n_frames - 1
+        if any(t is None for t in (pre_imgs, pre_hms, repro_hm, pre_hm_clss, repro_hm_cls)) or \
+                not (len(pre_imgs) == len(pre_hms) == len(pre_hm_clss) == n):
+            raise ValueError("the %d-frame model needs %d previous images / prior maps / class priors" % (n + 1, n))
+        if self.training:
+            raise RuntimeError("the HIP path is inference-only: call model.eval()")
+        return [self.engine().forward(x, list(pre_imgs), list(pre_hms), repro_hm, list(pre_hm_clss), repro_hm_cls)]
+
+    def engine(self):
+        if self._engine is None:
+            from ..engine_seq import EngineSeq
+            self._engine = EngineSeq(self)
+        return self._engine

@@ -422,7 +422,9 @@ class PackedC16:
         return 2.0 * M * 16 * self.cin * self.ks * self.ks
 
 
-def conv_c16(x, x2, pc, out):
+def conv_c16(x, x2, pc, out, mode=None):
+    """mode None: pc.mode (0 level0 / 1 fused stems); 2: image stem only; 3: cached image stem ``x`` + heat-map stem of
+    ``x2`` (sequence mode, sgta_conv_c16_f32)."""
     x, out = as_view(x), as_view(out)
     x2p, x2bs = None, 0
     if x2 is not None:
@@ -434,7 +436,7 @@ def conv_c16(x, x2, pc, out):
         meta = {"kernel": "conv_c16_kernel<%d>" % pc.ks, "flops": pc.flops(M), "bytes": 4.0 * M * (pc.cin + 16),
                 "exec_flops": pc.flops(M) * (200.0 / 196.0 if pc.mode == 1 else 1.0)}     # 148 + 52 padded k
     _lib.call("sgta_conv_c16_f32", x.ptr, x.bs, x2p, x2bs, pc.wt.data_ptr(), pc.bias.data_ptr(), out.ptr,
-              out.bs, x.B, x.H, x.W, pc.mode, _stream(), meta=meta)
+              out.bs, x.B, x.H, x.W, pc.mode if mode is None else mode, _stream(), meta=meta)
     return out
 
 

@@ -146,3 +146,55 @@ def dream_generic_post_process(dets_np, pp, num_classes):
             preds.append(item)
         ret.append(preds)
     return ret
+
+
+# ---- SGTADetector.pre_process on the device (sgta_detector.py:335-399) ------------------------------------------------
+def invert_affine(m):
+    """The inverse 2x3 map exactly as cv2.warpAffine builds it from ``M`` (imgwarp.cpp: D = 1 / det, double)."""
+    m = np.asarray(m, np.float64)
+    d = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22 = m[1, 1] * d, m[0, 0] * d
+    i00, i01, i10, i11 = a11, m[0, 1] * -d, m[1, 0] * -d, a22
+    b1 = -i00 * m[0, 2] - i01 * m[1, 2]
+    b2 = -i10 * m[0, 2] - i11 * m[1, 2]
+    return np.array([[i00, i01, b1], [i10, i11, b2]], np.float64)
+
+
+def transform_scale(height, width, opt):
+    """``_transform_scale`` (sgta_detector.py:335-365) at scale 1 (cv2.resize to the same size is the identity) ->
+    (c, s, inp_width, inp_height)."""
+    if getattr(opt, "fix_short", 0) > 0:
+        if height < width:
+            inp_h, inp_w = opt.fix_short, (int(width / height * opt.fix_short) + 63) // 64 * 64
+        else:
+            inp_h, inp_w = (int(height / width * opt.fix_short) + 63) // 64 * 64, opt.fix_short
+        return np.array([width / 2, height / 2], np.float32), np.array([width, height], np.float32), inp_w, inp_h
+    if getattr(opt, "fix_res", True):
+        return np.array([width / 2., height / 2.], np.float32), max(height, width) * 1.0, opt.input_w, opt.input_h
+    inp_h, inp_w = (height | opt.pad) + 1, (width | opt.pad) + 1
+    return np.array([width // 2, height // 2], np.float32), np.array([inp_w, inp_h], np.float32), inp_w, inp_h
+
+
+def pre_process(images_u8, opt, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), down_ratio=4, out=None):
+    """Batched ``SGTADetector.pre_process``: images_u8 uint8 [B,Hr,Wr,3] (device or host; one raw size per call) ->
+    (images f32 [B,3,inp_h,inp_w] on the device, list of the reference's ``meta`` dicts).  The affine warp + normalise
+    run in sgta_pre_process; only the 2x3 matrices are host work."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    img = images_u8 if torch.is_tensor(images_u8) else torch.from_numpy(np.ascontiguousarray(images_u8))
+    if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3:
+        raise ValueError("images must be uint8 [B,H,W,3]")
+    img = img.to(dev).contiguous()
+    B, Hr, Wr, _ = img.shape
+    c, s, inp_w, inp_h = transform_scale(Hr, Wr, opt)
+    t_in = get_affine_transform(c, s, 0, [inp_w, inp_h])
+    out_h, out_w = int(inp_h // down_ratio), int(inp_w // down_ratio)
+    t_out = get_affine_transform(c, s, 0, [out_w, out_h])
+    inv = torch.from_numpy(np.stack([invert_affine(t_in)] * B)).to(dev)
+    out = torch.empty((B, 3, inp_h, inp_w), dtype=torch.float32, device=dev) if out is None else out
+    _lib.call("sgta_pre_process", img.data_ptr(), inv.data_ptr(), _dev(np.asarray(mean, np.float32), torch.float32, dev).data_ptr(),
+              _dev(np.asarray(std, np.float32), torch.float32, dev).data_ptr(), out.data_ptr(), B, Hr, Wr, inp_h, inp_w,
+              torch.cuda.current_stream(dev).cuda_stream)
+    meta = {"c": c, "s": s, "height": Hr, "width": Wr, "out_height": out_h, "out_width": out_w, "inp_height": inp_h,
+            "inp_width": inp_w, "trans_input": t_in, "trans_output": t_out}
+    return out, [dict(meta) for _ in range(B)]

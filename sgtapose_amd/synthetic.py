@@ -149,6 +149,22 @@ def make_inputs_three(B, H, W, seed=317, n_kp=7):
             "pre_hm_cls": cur["pre_hm_cls"], "repro_hm_cls": cur["repro_hm_cls"]}
 
 
+def make_inputs_seq(B, H, W, T=4, seed=317, n_kp=7):
+    """Inputs of the T-frame model (DLAPlanAWindowSeq.forward): dict(x, pre_imgs, pre_hms, repro_hm, pre_hm_clss,
+    repro_hm_cls) with the T-1 previous frames OLDEST first.  The newest previous frame and the current one are the pair
+    of ``make_inputs(seed)``; the j-th older frame comes from ``make_inputs(seed + 1000 * j)`` (T = 3 reproduces
+    ``make_inputs_three``)."""
+    cur = make_inputs(B, H, W, seed, n_kp)
+    older = [make_inputs(B, H, W, seed + 1000 * j, n_kp) for j in range(T - 2, 0, -1)]
+    frames = older + [cur]
+    return {"x": cur["x"], "pre_imgs": [f["pre_img"] for f in frames], "pre_hms": [f["pre_hm"] for f in frames],
+            "repro_hm": cur["repro_hm"], "pre_hm_clss": [f["pre_hm_cls"] for f in frames],
+            "repro_hm_cls": cur["repro_hm_cls"]}
+
+
+SEQ_ARGS = ("x", "pre_imgs", "pre_hms", "repro_hm", "pre_hm_clss", "repro_hm_cls")
+
+
 def peaked_heatmaps(B, h, w, seed=317, n_kp=7, amp=0.9, floor=0.002):
     """Post-sigmoid-like heat-maps with one Gaussian blob (sigma 2) per class at a sub-pixel
     centre -- used for decode / keypoint parity since random-init logits are flat."""

@@ -955,3 +955,94 @@ def test_bench_cli_emits_one_json_line_with_roofline_and_parity():
     assert par["hm_max_abs"] < 1e-3 and par["reg_max_abs"] < 1e-3 and par["tracking_max_abs"] < 1e-3
     assert par["peaked_weights"]["integer_peaks_identical"] and par["peaked_weights"]["keypoint_l2_max_px"] < 1e-3
     assert r["cpu_baseline"]["cores"] >= 1 and "b8" in r["cpu_baseline"]
+
+
+# ---- T-frame temporal window (BASELINE configs[4]: seq_len 4) ---------------------------------------------------------
+def _seq_model(T, legacy_slip=False, sd=None, seed=3):
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from sgtapose_amd.synthetic import fill_state_dict_
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    m = create_model("dlapawdT_34", heads, default_head_conv(heads), default_opt(seq_len=T, legacy_slip=legacy_slip))
+    if sd is None:
+        sd = fill_state_dict_({k: v.clone() for k, v in m.state_dict().items()}, seed)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval(), sd
+
+
+@pytest.mark.parametrize("tag", ["128", "96x160"])
+def test_seq_model_at_three_frames_matches_reference(tag):
+    """dlapawdT_34 with seq_len 3 + legacy_slip = the reference's DLA_PlanAWindow_Three (golden head logits)."""
+    from sgtapose_amd.synthetic import SEQ_ARGS, make_inputs_seq
+    g = golden("fullnet_three_%s.npz" % tag)
+    B, H, W, seed, shared = [int(v) for v in g["meta"]]
+    m, _ = _seq_model(3, True, oracle.seq_keys_from_three(golden_state_dict(keys="model_keys_three.json")))
+    inp = make_inputs_seq(B, H, W, T=3, seed=seed)
+    mv = lambda v: [u.to(DEV) for u in v] if isinstance(v, list) else v.to(DEV)      # noqa: E731
+    out = m(*[mv(inp[k]) for k in SEQ_ARGS])[-1]
+    for k in ("hm", "reg", "wh", "tracking"):
+        err = float((out[k].cpu() - t(g[k])).abs().max())
+        assert err < 1e-3, (k, err)
+
+
+@pytest.mark.parametrize("T,B,H,W", [(4, 2, 128, 160), (4, 1, 96, 224), (5, 1, 128, 128)])
+def test_seq_model_four_frames_matches_oracle(T, B, H, W):
+    """seq_len 4 (and 5): no reference exists beyond T = 3, so the HIP path is checked against the oracle's
+    generalisation (itself pinned at T = 3)."""
+    from sgtapose_amd.synthetic import SEQ_ARGS, make_inputs_seq
+    m, sd = _seq_model(T)
+    inp = make_inputs_seq(B, H, W, T=T, seed=77)
+    mv = lambda v: [u.to(DEV) for u in v] if isinstance(v, list) else v.to(DEV)      # noqa: E731
+    out = m(*[mv(inp[k]) for k in SEQ_ARGS])[-1]
+    ref = oracle.plan_a_window_seq_forward(sd, *[inp[k] for k in SEQ_ARGS])
+    assert sorted(out) == ["hm", "reg", "tracking", "wh"]
+    for k in out:
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        assert out[k].shape == ref[k].shape and err < 1e-3, (k, err)
+    # the detector step works on it too (decode of every sample)
+    from sgtapose_amd.detector import BatchedDetector
+    _, dets = BatchedDetector(m).process_device(*[mv(inp[k]) for k in SEQ_ARGS])
+    assert dets["scores"].shape == (B, 7)
+
+
+def test_sequence_mode_stem_caching_is_bit_identical(model):
+    """a 4-frame video through SequenceDetector (image stem of frame t cached and reused
+    at step t+1) equals the stateless detector on the same frame pairs, bit for bit (same kernel arithmetic, the two
+    stems are only summed)."""
+    from sgtapose_amd.detector import BatchedDetector, SequenceDetector
+    from sgtapose_amd.synthetic import make_inputs
+    B, H, W = 2, 128, 160
+    frames = [make_inputs(B, H, W, seed=50 + i) for i in range(4)]
+    seq, ref = SequenceDetector(model), BatchedDetector(model)
+    prev_img = frames[0]["pre_img"].to(DEV)
+    for i, f in enumerate(frames):
+        img = f["x"].to(DEV)
+        pri = [f[k].to(DEV) for k in ("pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")]
+        out_s, det_s = seq.step_device(img, *pri, pre_image=prev_img if i == 0 else None)
+        out_s = {k: v.clone() for k, v in out_s.items()}
+        det_s = {k: v.clone() for k, v in det_s.items()}
+        out_r, det_r = ref.process_device(img, prev_img, *pri)
+        for k in out_r:
+            assert torch.equal(out_s[k], out_r[k]), (i, k)
+        for k in det_r:
+            assert torch.equal(det_s[k], det_r[k]), (i, k)
+        prev_img = img
+    with pytest.raises(ValueError):
+        SequenceDetector(model).step_device(img, *pri)          # first step without pre_image
+
+
+@pytest.mark.parametrize("Hr,Wr,inp_h,inp_w", [(480, 640, 480, 640), (720, 1280, 736, 1280), (257, 333, 128, 160), (96, 64, 128, 128)])
+def test_device_pre_process_matches_oracle_bit_exact(ops, Hr, Wr, inp_h, inp_w):
+    """sgta_pre_process (affine warp + normalise, SGTADetector.pre_process) against oracle.prepost.pre_process: every
+    float bit-identical (integer fixed-point warp, then the same two float32 roundings torch performs)."""
+    from types import SimpleNamespace
+    from oracle import prepost as op
+    from sgtapose_amd import prepost
+    rng = np.random.RandomState(Hr + Wr)
+    imgs = rng.randint(0, 256, (3, Hr, Wr, 3)).astype(np.uint8)
+    opt = SimpleNamespace(fix_short=0, fix_res=True, input_h=inp_h, input_w=inp_w, pad=31)
+    out, metas = prepost.pre_process(imgs, opt)
+    assert tuple(out.shape) == (3, 3, inp_h, inp_w) and len(metas) == 3
+    assert metas[0]["out_height"] == inp_h // 4 and metas[0]["trans_output"].shape == (2, 3)
+    for b in range(3):
+        ref = op.pre_process(imgs[b], metas[b]["trans_input"], inp_w, inp_h)
+        assert torch.equal(out[b:b + 1].cpu(), ref), b

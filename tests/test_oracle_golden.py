@@ -228,3 +228,16 @@ def test_three_frame_variant_matches_reference(tag):
     assert sorted(out) == ["hm", "reg", "tracking", "wh"]
     for k in out:
         assert torch.allclose(out[k], t(g[k]), atol=2e-5), (k, float((out[k] - t(g[k])).abs().max()))
+
+
+def test_seq_oracle_at_three_frames_is_the_reference_three_frame_model():
+    """The T-frame generalisation (BASELINE configs[4]) restricted to T = 3 with the reference's ``ppre_f = pre_feats``
+    slip must reproduce DLA_PlanAWindow_Three's outputs (fixture from the reference) -- the pin of the generalisation."""
+    from sgtapose_amd.synthetic import SEQ_ARGS, make_inputs_seq
+    g = golden("fullnet_three_128.npz")
+    B, H, W, seed, shared = [int(v) for v in g["meta"]]
+    sd = oracle.seq_keys_from_three(golden_state_dict(keys="model_keys_three.json"))
+    inp = make_inputs_seq(B, H, W, T=3, seed=seed)
+    out = oracle.plan_a_window_seq_forward(sd, *[inp[k] for k in SEQ_ARGS], legacy_slip=True)
+    for k in ("hm", "reg", "wh", "tracking"):
+        assert torch.allclose(out[k], t(g[k]), atol=1e-5), k

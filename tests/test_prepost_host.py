@@ -41,3 +41,27 @@ def test_reference_shaped_assembly_from_device_outputs():
     for b in range(len(items)):
         assert np.array_equal(op.get_final_kps(items[b], cs["K"]), g["final_kps"][b])
     assert prepost.MISSING == -999.999 * 4
+
+
+def test_warp_affine_restatement_is_a_bilinear_warp_and_matches_host_mirror():
+    """oracle.prepost.warp_affine_u8 (OpenCV's published 8-bit warpAffine, unpinned: OpenCV absent) against scipy's float
+    bilinear interpolation: within half a grey level (the 1/32-pixel coordinate grid + integer rounding); and the
+    product's host-side matrix inversion equals the oracle's."""
+    from scipy.ndimage import gaussian_filter, map_coordinates
+    from oracle import prepost as op
+    from sgtapose_amd import prepost as hp
+    rng = np.random.RandomState(0)
+    img = np.clip(gaussian_filter(rng.randint(0, 256, (120, 160, 3)).astype(np.float64), (3, 3, 0)), 0, 255).astype(np.uint8)
+    for (c, s, size, tol) in ((np.array([80., 60.], np.float32), 160.0, (128, 96), 0.75),
+                              (np.array([80., 60.], np.float32), 100.0, (64, 64), 0.75),
+                              (np.array([60., 70.], np.float32), 400.0, (96, 128), 2.5)):
+        M = op.get_affine_transform(c, s, 0, list(size))
+        w = op.warp_affine_u8(img, M, size)
+        iM = op.invert_affine(M)
+        assert np.array_equal(iM, hp.invert_affine(M))
+        ys, xs = np.mgrid[0:size[1], 0:size[0]]
+        sx = iM[0, 0] * xs + iM[0, 1] * ys + iM[0, 2]
+        sy = iM[1, 0] * xs + iM[1, 1] * ys + iM[1, 2]
+        ref = np.stack([map_coordinates(img[..., k].astype(np.float64), [sy, sx], order=1, mode="grid-constant", cval=0)
+                        for k in range(3)], -1)
+        assert np.abs(w.astype(np.float64) - ref).max() <= tol
