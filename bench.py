@@ -38,7 +38,8 @@ ARGS = ("x", "pre_img", "pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")
 PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD at 2.4 GHz
 PEAK_TFLOPS_BF16_MFMA = 2500.0      # dense bf16 MFMA (the guide's ~2.5 PF; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0               # HBM3E spec
-PMC_TABLE = os.path.join(REPO, "profiles", "r02_pmc_step_by_kernel.csv")
+PMC_TABLES = {"f32": os.path.join(REPO, "profiles", "r02_pmc_step_by_kernel.csv"),
+              "bf16": os.path.join(REPO, "profiles", "r02_pmc_step_by_kernel_bf16.csv")}
 
 
 def log(*a):
@@ -135,6 +136,7 @@ def pmc_traffic(kernel, workload):
     workload and the commit the passes were made at).  bench.py cannot collect counters itself; the table is used only
     when its workload matches this run's, otherwise traffic is null.  gfx950 correction per the guide: FETCH_SIZE
     tallies the 128-byte requests of 16-B/lane streams at 64 bytes -> doubled."""
+    PMC_TABLE = PMC_TABLES.get(workload.get("dtype"), PMC_TABLES["f32"])
     try:
         import csv
         meta = json.load(open(PMC_TABLE + ".meta.json"))

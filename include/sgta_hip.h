@@ -291,6 +291,28 @@ int sgta_post_process(const float* scores, const long long* cts, const float* ct
 int sgta_pre_process(const unsigned char* images, const double* inv_trans, const float* mean, const float* stdv,
                      float* out, int B, int Hr, int Wr, int Ho, int Wo, sgta_stream_t stream);
 
+/* ---- pose step downstream of the key-points, fp64, one thread per frame ---------------
+ * sgta_pnp_batched = solve_pnp (sgtapose/geometric_vision.py:43-116: cv2.solvePnP EPNP + ITERATIVE refinement) and, when
+ * next_proj != NULL, is_pnp (:283-310): the pose of each frame applied to ``next_x3d`` and projected with ``camK`` (on a
+ * failed solve the detections ``x2d`` themselves are returned, as the reference does).  x3d f64 [B,K,3] object points,
+ * x2d f64 [B,K,2] detections in raw-image pixels; valid u8 [B,K] or NULL (NULL: a key-point is used iff one of its
+ * coordinates exceeds the detector's missing marker -999.999*4, sgta_detector.py:469-472); camK f64 [9] row-major.
+ * Outputs: ok u8 [B], t f64 [B,3], quat_xyzw f64 [B,4] (convert_rvec_to_quaternion), next_proj f64 [B,K,2].  4 <= K <= 16.
+ * OpenCV is absent from the image: EPnP and the refinement follow the published algorithms (see pnp.hip); unpinned
+ * against the library, checked against oracle/pnp.py and against the poses the test data were generated from. */
+int sgta_pnp_batched(const double* x3d, const double* x2d, const unsigned char* valid, const double* camK,
+                     const double* next_x3d, unsigned char* ok, double* t_out, double* quat_xyzw, double* next_proj,
+                     int B, int K, sgta_stream_t stream);
+
+/* The reference's Gauss-Newton pose refinement: ``extern "C" LM(double*, ..., int)`` of libtestso_final.so with its python
+ * twin GN / fun / dfun (sgtapose/rf_tools/LM.py:128-234, :256-266), batched.  value0 f64 [B,7] = (qw,qx,qy,qz,tx,ty,tz);
+ * x2d [B,K,2], x3d [B,K,3], valid u8 [B,K] or NULL, weights f64 [B,K,2] or NULL (= 1); out f64 [B,7]; iters int32 [B] or
+ * NULL.  Same iteration as the reference: value -= (float32(J^T J) + 1e-4 I)^-1 J^T f while sum|delta| > 1e-4, at most
+ * max_iter (200) times, the reference's Jacobian slip (y rows: d/dqz = d/dqy) included; a NaN update ends the loop. */
+int sgta_gn_refine(const double* value0, const double* x2d, const double* x3d, const unsigned char* valid,
+                   const double* weights, const double* camK, double* out, int* iters, int B, int K, int max_iter,
+                   sgta_stream_t stream);
+
 /* ---- bf16 data path (BASELINE configs[2]: bf16 feature maps / weights, fp32 accumulate / softmax / LayerNorm / decode) ----
  * Feature maps are bf16 CHANNELS-LAST [N,H,W,ld] (``ld`` = channels of the underlying buffer, so a tensor may be a
  * channel slice of a concatenation buffer); weights are bf16 in the packed LDS-image layouts produced by

@@ -53,6 +53,8 @@ SIGNATURES = {
     "sgta_window_gather_bf16": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_window_scatter_bf16": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "sgta_pre_process": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_pnp_batched": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "sgta_gn_refine": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "sgta_softargmax": [_p, _p, _i, _i, _i, _i, _f, _f, _p],
 }
 

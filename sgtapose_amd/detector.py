@@ -73,6 +73,17 @@ class BatchedDetector:
         dets_np = {k: v.detach().cpu().numpy() for k, v in dets.items()}
         return prepost.dream_generic_post_process(dets_np, pp, self.K), pp["final_kps"]
 
+    def next_frame_priors(self, final_kps, prev_x3d, next_x3d, camera_K, metas):
+        """The loop between two frames, on the device (``SGTADetector._get_further_dt_pnp_inputs``,
+        sgta_detector.py:455-497): PnP on this frame's final key-points (missing ones skipped) against the robot's 3-D
+        key-points, the pose applied to the next frame's 3-D key-points, and the four prior maps rendered from those
+        projections.  final_kps [B,K,2] f64 (post_process_device), prev_x3d / next_x3d [B,K,3].
+        -> (pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, pnp dict)."""
+        from . import pnp
+        r = pnp.solve_pnp(prev_x3d, final_kps, camera_K, next_points=next_x3d)
+        maps = self.render_inputs(final_kps, r["next_kp_projs_est"], metas)
+        return maps + (r,)
+
     @staticmethod
     def keypoints(dets):
         """[B,K,3] float32 (x + reg_x, y + reg_y, score) -- the tensor that is all-gathered across ranks."""

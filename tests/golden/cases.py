@@ -117,3 +117,28 @@ def prepost_case():
             "regs": regs, "tracking": trk}
     return dict(K=K, inp_w=inp_w, inp_h=inp_h, out_w=out_w, out_h=out_h, raws=raws, c=c, s=s, prev=prev, nxt=nxt,
                 has_prior=has_prior, dets=dets, out_thresh=0.1)
+
+
+def pnp_case():
+    """Seeded pose problems for the PnP / Gauss-Newton fixtures: a 7-key-point 'robot' (metres), a camera like the
+    reference's (fx = fy = 615.5, 640x480), poses in front of the camera, pixel noise, samples with missing key-points."""
+    rng = np.random.RandomState(77)
+    K = np.array([[615.5, 0.0, 320.0], [0.0, 615.5, 240.0], [0.0, 0.0, 1.0]])
+    x3d = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.33], [0.1, -0.05, 0.65], [0.3, 0.0, 0.75], [0.45, 0.1, 0.6],
+                    [0.55, 0.0, 0.45], [0.6, -0.1, 0.3]])
+    cases_ = []
+    for i in range(12):
+        ax = rng.randn(3)
+        ax /= np.linalg.norm(ax)
+        ang = rng.uniform(0.2, 2.6)
+        rvec = ax * ang
+        t = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(1.0, 2.5)])
+        noise = rng.randn(7, 2) * (0.0 if i < 3 else 0.7)
+        valid = np.ones(7, bool)
+        if i % 4 == 3:
+            valid[rng.choice(7, 2, replace=False)] = False
+        if i == 10:
+            valid[:] = False
+            valid[[0, 3, 5, 6]] = True                       # exactly four points
+        cases_.append(dict(rvec=rvec, t=t, noise=noise, valid=valid))
+    return K, x3d, cases_

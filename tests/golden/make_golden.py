@@ -228,6 +228,38 @@ def three_frames():
                  **{k: v for k, v in out.items()})
 
 
+def pnp_ops():
+    """Gauss-Newton refinement of rf_tools/LM.py (fun / dfun / GN: the python twin of the C ``LM``), run from the
+    reference's own file.  LM.py loads a .so from a hard-coded absolute path at import and imports cv2: both are stubbed
+    (neither is touched by fun / dfun / GN)."""
+    import ctypes
+    import ref_import
+    from oracle import pnp as opnp
+    load_reference()
+    real = ctypes.cdll.LoadLibrary
+    ctypes.cdll.LoadLibrary = lambda path: None
+    try:
+        lm = ref_import._load("reflib.rf_tools_LM", os.path.join(ref_import.REF, "rf_tools/LM.py"))
+    finally:
+        ctypes.cdll.LoadLibrary = real
+    K, x3d, cs = cases.pnp_case()
+    arrs = {}
+    for i, c in enumerate(cs):
+        v = c["valid"]
+        R = opnp.rodrigues(c["rvec"])
+        x2d = opnp.project(K, R, c["t"], x3d) + c["noise"]
+        q = opnp.quat_xyzw_from_rvec(c["rvec"] + 0.02)                     # a start near the pose, as PnP provides
+        value0 = np.array([q[3], q[0], q[1], q[2], *(c["t"] + 0.01)])
+        w = [[1.0, 1.0]] * int(v.sum())
+        args = (x2d[v].tolist(), x3d[v].tolist(), w, K)
+        arrs["f_%d" % i] = lm.fun(value0, *args)
+        arrs["df_%d" % i] = lm.dfun(value0, *args)
+        arrs["gn_%d" % i] = lm.GN(value0, *args)
+        arrs["x2d_%d" % i] = x2d
+        arrs["value0_%d" % i] = value0
+    save("pnp_ops.npz", **arrs)
+
+
 def peaked():
     """Second weight set (peaked heat-maps): reference network -> sigmoid ->
     dream_generic_decode; the decode dictionaries hold real key-points (scores > 0)."""
@@ -243,6 +275,9 @@ def main():
         return
     if "--peaked-only" in sys.argv:
         peaked()
+        return
+    if "--pnp-only" in sys.argv:
+        pnp_ops()
         return
     if "--prepost-only" in sys.argv:
         prepost_ops()
@@ -265,6 +300,7 @@ def main():
     fullnet(model, "480", 1, 480, 480, 320)
     fullnet(model, "480x640", 1, 480, 640, 321)
     peaked()
+    pnp_ops()
 
 
 if __name__ == "__main__":

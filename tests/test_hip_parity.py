@@ -1046,3 +1046,69 @@ def test_device_pre_process_matches_oracle_bit_exact(ops, Hr, Wr, inp_h, inp_w):
     for b in range(3):
         ref = op.pre_process(imgs[b], metas[b]["trans_input"], inp_w, inp_h)
         assert torch.equal(out[b:b + 1].cpu(), ref), b
+
+
+# ---- pose step downstream of the key-points ---------------------------------------------------
+def test_batched_pnp_and_gauss_newton_match_oracle(ops, model):
+    """sgta_pnp_batched / sgta_gn_refine against oracle.pnp (solve_pnp / is_pnp unpinned vs OpenCV, GN pinned vs the
+    reference's python twin through tests/golden/pnp_ops.npz): poses to 1e-7, projections to 1e-5 px, the generating
+    pose recovered; missing key-points given by the detector's -999.999*4 marker."""
+    from oracle import pnp as op
+    from sgtapose_amd import pnp
+    from test_oracle_golden import _gn_converged, _pnp_problems
+    op, K, x3d, probs = _pnp_problems()
+    B = len(probs)
+    x2d = np.stack([p["x2d"] for p in probs])
+    for b, p in enumerate(probs):
+        x2d[b][~p["v"]] = -999.999 * 4                              # as SGTADetector._get_final_kps marks them
+    X = np.stack([x3d] * B)
+    r = pnp.solve_pnp(X, x2d, K, next_points=X)
+    assert r["retval"].cpu().numpy().tolist() == [1] * B
+    for b, p in enumerate(probs):
+        v = p["v"]
+        ok, t, q = op.solve_pnp(x3d[v], p["x2d"][v], K)
+        tq = r["quaternion"][b].cpu().numpy()
+        assert np.abs(r["translation"][b].cpu().numpy() - t).max() < 1e-7, b
+        assert min(np.abs(tq - q).max(), np.abs(tq + q).max()) < 1e-7, b
+        _, proj = op.is_pnp(x3d[v], p["x2d"][v], x3d, p["x2d"], K)
+        assert np.abs(r["next_kp_projs_est"][b].cpu().numpy() - proj).max() < 1e-5, b
+        if np.abs(p["c"]["noise"]).max() == 0:
+            assert np.abs(r["translation"][b].cpu().numpy() - p["c"]["t"]).max() < 1e-8
+    # fewer than four usable key-points: retval 0 and the detections stand in for the projections (is_pnp's else branch)
+    bad = x2d[:2].copy()
+    bad[:, 3:] = -999.999 * 4
+    rb = pnp.solve_pnp(X[:2], bad, K, next_points=X[:2])
+    assert rb["retval"].cpu().numpy().tolist() == [0, 0] and np.array_equal(rb["next_kp_projs_est"].cpu().numpy(), bad)
+    # Gauss-Newton refinement: where the reference converged, the same end value; f / J through one step from value0
+    v0 = np.stack([p["value0"] for p in probs])
+    valid = np.stack([p["v"] for p in probs]).astype(np.uint8)
+    q, T, it = pnp.register_GN_C(np.stack([p["x2d"] for p in probs]), X, v0[:, :4], v0[:, 4:], None, K, valid=valid)
+    got = torch.cat([q, T], 1).cpu().numpy()
+    n_conv = 0
+    for b, p in enumerate(probs):
+        if _gn_converged(op, K, x3d, p):
+            n_conv += 1
+            assert np.abs(got[b] - p["gn"]).max() < 1e-5, b
+    assert n_conv >= 3
+    q1, T1, it1 = pnp.register_GN_C(np.stack([p["x2d"] for p in probs]), X, v0[:, :4], v0[:, 4:], None, K, valid=valid, max_iter=1)
+    for b, p in enumerate(probs):
+        v = p["v"]
+        w = [[1.0, 1.0]] * int(v.sum())
+        with np.errstate(all="ignore"):
+            one = op.gn_refine(p["value0"], p["x2d"][v], x3d[v], w, K, max_iter=1)
+        assert np.allclose(torch.cat([q1, T1], 1)[b].cpu().numpy(), one, rtol=1e-6, atol=1e-9), b
+    assert it1.cpu().numpy().tolist() == [1] * B
+    # the loop between two frames on the device: final key-points -> PnP -> projections -> the four prior maps
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd import prepost
+    det = BatchedDetector(model)
+    c, s = np.array([320.0, 240.0], np.float32), 640.0
+    meta = dict(c=c, s=s, width=640, height=480, inp_width=640, inp_height=480, out_width=160, out_height=120,
+                trans_input=prepost.get_affine_transform(c, s, 0, [640, 480]),
+                trans_output=prepost.get_affine_transform(c, s, 0, [160, 120]))
+    maps = det.next_frame_priors(torch.from_numpy(x2d).to(DEV), X, X, K, [meta] * B)
+    assert tuple(maps[0].shape) == (B, 1, 480, 640) and tuple(maps[3].shape) == (B, 7, 120, 160)
+    ref_maps = det.render_inputs(x2d, r["next_kp_projs_est"], [meta] * B)
+    for a, b_ in zip(maps[:4], ref_maps):
+        assert torch.equal(a, b_)
+    assert float(maps[1].max()) == 1.0

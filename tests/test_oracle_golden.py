@@ -241,3 +241,67 @@ def test_seq_oracle_at_three_frames_is_the_reference_three_frame_model():
     out = oracle.plan_a_window_seq_forward(sd, *[inp[k] for k in SEQ_ARGS], legacy_slip=True)
     for k in ("hm", "reg", "wh", "tracking"):
         assert torch.allclose(out[k], t(g[k]), atol=1e-5), k
+
+
+# ---- pose step downstream of the key-points ---------------------------------------------------
+def _pnp_problems():
+    from oracle import pnp as op
+    K, x3d, cs = cases.pnp_case()
+    g = golden("pnp_ops.npz")
+    out = []
+    for i, c in enumerate(cs):
+        out.append(dict(i=i, c=c, v=c["valid"], x2d=g["x2d_%d" % i], value0=g["value0_%d" % i], f=g["f_%d" % i],
+                        df=g["df_%d" % i], gn=g["gn_%d" % i]))
+    return op, K, x3d, out
+
+
+def _gn_converged(op, K, x3d, p):
+    """The reference's GN ended at a fixed point (finite, one more step moves it by <= 1e-4): its end value is then
+    reproducible; where it diverged (NaN / wandering for 200 steps) the trajectory is chaotic and only the NaN fall-back
+    of the caller (analysis.py:209-214) is defined."""
+    if not np.all(np.isfinite(p["gn"])):
+        return False
+    w = [[1.0, 1.0]] * int(p["v"].sum())
+    nxt = op.gn_refine(p["gn"], p["x2d"][p["v"]], x3d[p["v"]], w, K, max_iter=1)
+    return bool(np.abs(nxt - p["gn"]).sum() <= 1e-4)
+
+
+def test_gauss_newton_refinement_matches_reference_python_twin():
+    """oracle.pnp.gn_fun / gn_dfun / gn_refine against fun / dfun / GN of the reference's rf_tools/LM.py (fixture): residuals
+    and Jacobian (incl. the reference's d/dqz slip) to 1e-9 relative, the converged end values to 1e-5."""
+    op, K, x3d, probs = _pnp_problems()
+    n_conv = 0
+    for p in probs:
+        v = p["v"]
+        w = [[1.0, 1.0]] * int(v.sum())
+        f = op.gn_fun(p["value0"], p["x2d"][v], x3d[v], w, K)
+        df = op.gn_dfun(p["value0"], p["x2d"][v], x3d[v], w, K)
+        assert np.allclose(f, p["f"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(df, p["df"], rtol=1e-9, atol=1e-9 * np.abs(p["df"]).max())
+        if _gn_converged(op, K, x3d, p):
+            n_conv += 1
+            with np.errstate(all="ignore"):
+                got = op.gn_refine(p["value0"], p["x2d"][v], x3d[v], w, K)
+            assert np.allclose(got, p["gn"], atol=1e-5), p["i"]
+    assert n_conv >= 3
+
+
+def test_solve_pnp_recovers_the_generating_pose():
+    """oracle.pnp.solve_pnp (EPnP + iterative refinement, unpinned: OpenCV absent) recovers the poses the noise-free
+    problems were generated from to 1e-9, the noisy ones to the noise level, with 7, 5 and 4 points; is_pnp's
+    projections follow."""
+    op, K, x3d, probs = _pnp_problems()
+    for p in probs:
+        c, v = p["c"], p["v"]
+        ok, t, q = op.solve_pnp(x3d[v], p["x2d"][v], K)
+        assert ok
+        R, Rt = op.R_from_quat_xyzw(q), op.rodrigues(c["rvec"])
+        tol = 1e-9 if np.abs(c["noise"]).max() == 0 else 5e-2
+        assert np.abs(t - c["t"]).max() < tol and np.abs(R - Rt).max() < tol, p["i"]
+        # the minimum of the reprojection error: no worse than the generating pose
+        e_fit = np.sum((op.project(K, R, t, x3d[v]) - p["x2d"][v]) ** 2)
+        e_true = np.sum((op.project(K, Rt, c["t"], x3d[v]) - p["x2d"][v]) ** 2)
+        assert e_fit <= e_true + 1e-9
+        _, proj = op.is_pnp(x3d[v], p["x2d"][v], x3d, p["x2d"], K)
+        assert np.allclose(proj, op.project(K, R, t, x3d), atol=1e-9)
+    assert op.solve_pnp(x3d[:3], probs[0]["x2d"][:3], K)[0] is False

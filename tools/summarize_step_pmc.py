@@ -16,15 +16,20 @@ def load(d):
     rows = list(csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])))
     by = collections.OrderedDict()
     for r in rows:
-        k = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:48])
+        k = (int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:64])
         by.setdefault(k, {})[r["Counter_Name"]] = float(r["Counter_Value"])
     return by
 
 
 def family(name):
     fam = name.split("<")[0]
-    if "wino" in fam and "<" in name:                 # keep the tile shape: same spelling as bench.py's table
-        fam += "<%s>" % name.split("<")[1].split(",")[0].strip()
+    args = [a.strip() for a in name.split("<")[1].split(">")[0].split(",")] if "<" in name else []
+    if "wino" in fam and args:                        # keep the tile shape: same spelling as bench.py's table
+        fam += "<%s>" % args[0]
+    elif fam == "conv_bf16_kernel" and len(args) >= 5:    # <KS, S, KC, NPF, NA> -> bench.py's <KS,S,NA>
+        fam += "<%s,%s,%s>" % (args[0], args[1], args[4])
+    elif fam == "dcn_bf16_kernel" and len(args) >= 2:     # <NPF, NA> -> <NA>
+        fam += "<%s>" % args[1]
     return fam
 
 
