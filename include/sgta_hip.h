@@ -324,10 +324,11 @@ int sgta_gn_refine(const double* value0, const double* x2d, const double* x3d, c
  * x_bytes / wt_bytes: bytes addressable from x / wt (< 2^31).  wt: [Cout tile][Cin/kc][tap][32*na][kc] bf16, rows
  * XOR-swizzled in 16-byte pieces.  out_mode 0: y bf16 NHWC [N,Ho,Wo,ldy]; 2: y f32 NHWC; 1: y f32 NCHW [N,Cout,Ho,Wo]
  * with sigmoid on channels < nsig (SGTADetector._sigmoid_output, sgta_detector.py:854-862).  kc = 16 (3x3) / 32 (1x1),
- * Cin % kc == 0; na in {1,2,4} (2 max for stride 2); log_tw = log2 of the tile width (3..6). */
+ * Cin % kc == 0; na in {1,2,4} (2 max for stride 2); npf = 32-position fragments per wave (2: 512-position tiles, 1: 256;
+ * stride 2 needs 1); log_tw = log2 of the tile width (3..6). */
 int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt_bytes, const float* bias,
                    const void* res, int ldr, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
-                   int ks, int stride, int kc, int na, int log_tw, int act, int out_mode, int nsig,
+                   int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
                    sgta_stream_t stream);
 
 /* DeformConv (dla.py:538-550) = lbin/DCNv2 modulated deformable 3x3 conv + folded BN + ReLU on bf16 NHWC maps -- the

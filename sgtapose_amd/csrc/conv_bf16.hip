@@ -173,29 +173,57 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
 
   // ---- epilogue: C/D layout col = lane & 31 (position), row = (q & 3) + 8 (q >> 2) + 4 h (output channel) ----------
   const long HWo = (long)a.Ho * a.Wo;
+  auto value4 = [&](int i, int f, int g4, long pix) {          // bias + residual + activation of 4 consecutive channels
+    const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (co0 < a.Cout) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[i][f][4 * g4 + j] + bv[j];
+      if (a.res) {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + pix * a.ldr + co0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+      }
+      if (a.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+      }
+    }
+    return v;
+  };
 #pragma unroll
   for (int f = 0; f < NPF; ++f) {
-    if (prem[f] < 0) continue;
+    if (prem[f] < 0) continue;                                 // both lane halves of a position agree (same r)
     const long pix = (long)pn[f] * HWo + prem[f];
+    if (a.out_mode == 0 && (a.Cout & 7) == 0) {
+      // bf16 NHWC: a lane holds channels {8 g4 + 4 h ..+3}; exchanging the odd group of the lower lane half with the even
+      // group of the upper half (v_permlane32_swap) gives every lane 8 consecutive channels = one 16-byte store, and the
+      // two halves of a position 32 contiguous bytes (8-byte stores were written back sector by sector: 2.5x the bytes)
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const bf16x4 pb = __builtin_convertvector(value4(i, f, 2 * m, pix), bf16x4);
+          const bf16x4 qb = __builtin_convertvector(value4(i, f, 2 * m + 1, pix), bf16x4);
+          const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
+          const int co = ct * TC + i * 32 + 16 * m + 8 * h;
+          if (co < a.Cout)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.y) + pix * a.ldy + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
         if (co0 >= a.Cout) continue;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[i][f][4 * g4 + j] + bv[j];
-        if (a.res) {
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + pix * a.ldr + co0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
-        }
-        if (a.act == 1) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-        }
+        const f32x4 v = value4(i, f, g4, pix);
         if (a.out_mode == 0) {
           *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + pix * a.ldy + co0) = __builtin_convertvector(v, bf16x4);
         } else if (a.out_mode == 2) {
@@ -235,36 +263,46 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
 // allocation that may be addressed, < 2^31); wt: sgta_conv_bf16_pack layout for (ks, stride, kc, na); bias f32
 // [n_ct*32*na]; res: bf16 NHWC [N,Ho,Wo,ldr] or NULL (added before the activation); out_mode 0: y bf16 NHWC [..,ldy],
 // 2: y f32 NHWC [..,ldy], 1: y f32 NCHW [N,Cout,Ho,Wo] with sigmoid on channels < nsig.  act: 0 none, 1 ReLU.
-// log_tw: log2 of the tile width (3..6).  Cin % kc == 0, kc in {16 (3x3), 32 (1x1)}.
+// npf: 32-position fragments per wave (2: 512-position tiles; 1: 256; stride 2 needs 1); log_tw: log2 of the tile width
+// (3..6).  Cin % kc == 0, kc in {16 (3x3), 32 (1x1)}.
 extern "C" int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt_bytes, const float* bias,
                               const void* res, int ldr, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
-                              int ks, int stride, int kc, int na, int log_tw, int act, int out_mode, int nsig,
+                              int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
                               hipStream_t st) {
   if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SGTA_EBADARG;
   if (x_bytes <= 0 || x_bytes > 0x7fffffffL || wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if (Cin % kc || (ldx % 8) || log_tw < 3 || log_tw > 6 || act < 0 || act > 1 || out_mode < 0 || out_mode > 2) return SGTA_EBADARG;
   if (out_mode != 1 && (ldy % 4 || Cout % 4)) return SGTA_EBADARG;
+  if (out_mode == 0 && Cout % 8 == 0 && (ldy % 8 || ((uintptr_t)y & 15))) return SGTA_EBADARG;     // 16-byte stores
   if (res && ldr % 4) return SGTA_EBADARG;
   CbArgs a;
   a.x = x; a.x_bytes = x_bytes; a.ldx = ldx; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
   a.res = reinterpret_cast<const __bf16*>(res); a.ldr = ldr; a.y = y; a.ldy = ldy;
   a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cout = Cout;
   a.nchunks = Cin / kc; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act; a.out_mode = out_mode; a.nsig = nsig;
-  const int npf = (ks == 3 && stride == 2) ? 1 : 2;
+  if (npf != 1 && npf != 2) return SGTA_EBADARG;
   const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
   a.n_rt = cdiv((long)N * (a.Ho + 1), TR);
   a.n_xt = cdiv(a.Wo, TW);
-  if (ks == 3 && stride == 1 && kc == 16) {
+  if (ks == 3 && stride == 1 && kc == 16 && npf == 2) {
     if (na == 1) return cb_launch<3, 1, 16, 2, 1>(a, st);
     if (na == 2) return cb_launch<3, 1, 16, 2, 2>(a, st);
     if (na == 4) return cb_launch<3, 1, 16, 2, 4>(a, st);
-  } else if (ks == 3 && stride == 2 && kc == 16) {
+  } else if (ks == 3 && stride == 1 && kc == 16 && npf == 1) {       // half-size tiles: small maps (work-group count / tail)
+    if (na == 1) return cb_launch<3, 1, 16, 1, 1>(a, st);
+    if (na == 2) return cb_launch<3, 1, 16, 1, 2>(a, st);
+    if (na == 4) return cb_launch<3, 1, 16, 1, 4>(a, st);
+  } else if (ks == 3 && stride == 2 && kc == 16 && npf == 1) {
     if (na == 1) return cb_launch<3, 2, 16, 1, 1>(a, st);
     if (na == 2) return cb_launch<3, 2, 16, 1, 2>(a, st);
-  } else if (ks == 1 && stride == 1 && kc == 32) {
+  } else if (ks == 1 && stride == 1 && kc == 32 && npf == 2) {
     if (na == 1) return cb_launch<1, 1, 32, 2, 1>(a, st);
     if (na == 2) return cb_launch<1, 1, 32, 2, 2>(a, st);
     if (na == 4) return cb_launch<1, 1, 32, 2, 4>(a, st);
+  } else if (ks == 1 && stride == 1 && kc == 32 && npf == 1) {
+    if (na == 1) return cb_launch<1, 1, 32, 1, 1>(a, st);
+    if (na == 2) return cb_launch<1, 1, 32, 1, 2>(a, st);
+    if (na == 4) return cb_launch<1, 1, 32, 1, 4>(a, st);
   }
   return SGTA_EBADARG;
 }

@@ -308,6 +308,7 @@ static int launch_conv(ConvArgs& a, int act, int res_mode, int tile, hipStream_t
     if (act == 1 && res_mode == 1) return launch_tile<KS, false, 1, 1>(a, tile, st);
     if (act == 1 && res_mode == 2) return launch_tile<KS, false, 1, 2>(a, tile, st);
     if (act == 2 && res_mode == 0) return launch_tile<KS, false, 2, 0>(a, tile, st);
+    if (KS == 1 && act == 0 && res_mode == 1) return launch_tile<KS, false, 0, 1>(a, tile, st);   // T-frame cat-MLP partial sums
   }
   return SGTA_EBADARG;
 }

@@ -85,6 +85,15 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
 
+  // the 27 offset / mask values of this lane's pixels, fetched once (not a dependent load in front of every tap)
+  float omv[NPF][27];
+#pragma unroll
+  for (int f = 0; f < NPF; ++f) {
+    const float* o = a.om + (pix[f] >= 0 ? pix[f] : 0) * a.ldo;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) omv[f][j] = o[j];
+  }
+
   stage(0, 0);
   int q = 0;
 #pragma unroll 1
@@ -95,10 +104,9 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
 #pragma unroll
     for (int f = 0; f < NPF; ++f) {
       float dy = 0.0f, dx = 0.0f, ml = 0.0f;
-      if (pix[f] >= 0) {
-        const float* o = a.om + pix[f] * a.ldo;
-        dy = o[2 * t]; dx = o[2 * t + 1]; ml = o[18 + t];
-      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j)                     // register array indexed by the (runtime) tap: select chain
+        if (j == t) { dy = omv[f][2 * j]; dx = omv[f][2 * j + 1]; ml = omv[f][18 + j]; }
       const float m = 1.0f / (1.0f + __expf(-ml));
       const float py = (float)(py0[f] - 1 + t / 3) + dy, px = (float)(px0[f] - 1 + t % 3) + dx;
       const bool inside = pix[f] >= 0 && py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
@@ -120,26 +128,31 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
 #pragma unroll 1
     for (int g = 0; g < a.ngroups; ++g, ++q) {
       const int st = q & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // all 16 corner runs of this 64-channel group in flight together (the blend of k-step s waits only for its own)
+      bf16x8 cv[4][NPF][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int f = 0; f < NPF; ++f)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            cv[s][f][k] = *reinterpret_cast<const bf16x8*>(a.x + coff[f][k] + g * 64 + s * 16 + h * 8);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * NPF) : "memory");          // the weight DMA of this stage (older than the loads)
       __builtin_amdgcn_s_barrier();
       if (q + 1 < nstages) stage(q + 1, st ^ 1);
       const unsigned char* As = smem + st * STAGE;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int c = g * 64 + s * 16 + h * 8;
         bf16x8 bfr[NPF];
 #pragma unroll
         for (int f = 0; f < NPF; ++f) {
-          bf16x8 cv[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) cv[k] = *reinterpret_cast<const bf16x8*>(a.x + coff[f][k] + c);
           float v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float s0 = cw[f][0] * (float)cv[0][j];
-            s0 = __builtin_fmaf(cw[f][1], (float)cv[1][j], s0);
-            s0 = __builtin_fmaf(cw[f][2], (float)cv[2][j], s0);
-            v[j] = __builtin_fmaf(cw[f][3], (float)cv[3][j], s0);
+            float s0 = cw[f][0] * (float)cv[s][f][0][j];
+            s0 = __builtin_fmaf(cw[f][1], (float)cv[s][f][1][j], s0);
+            s0 = __builtin_fmaf(cw[f][2], (float)cv[s][f][2][j], s0);
+            v[j] = __builtin_fmaf(cw[f][3], (float)cv[s][f][3][j], s0);
           }
           typedef float f32x8 __attribute__((ext_vector_type(8)));
           const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
@@ -157,23 +170,37 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
     }
   }
 
+  // epilogue: bias + ReLU, then v_permlane32_swap pairs the two lane halves' channel groups so that every lane stores 8
+  // consecutive channels (16 bytes) and a pixel's two lanes 32 contiguous bytes (see conv_bf16.hip)
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto value4 = [&](int i, int f, int g4) {
+    const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (co0 < a.Cout) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[i][f][4 * g4 + j] + bv[j];
+        if (a.act == 1) v[j] = fmaxf(v[j], 0.0f);
+      }
+    }
+    return v;
+  };
 #pragma unroll
   for (int f = 0; f < NPF; ++f) {
     if (pix[f] < 0) continue;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
-        if (co0 >= a.Cout) continue;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = acc[i][f][4 * g4 + j] + bv[j];
-          if (a.act == 1) v[j] = fmaxf(v[j], 0.0f);
-        }
-        *reinterpret_cast<bf16x4*>(a.y + pix[f] * a.ldy + co0) = __builtin_convertvector(v, bf16x4);
+      for (int m = 0; m < 2; ++m) {
+        const bf16x4 pb = __builtin_convertvector(value4(i, f, 2 * m), bf16x4);
+        const bf16x4 qb = __builtin_convertvector(value4(i, f, 2 * m + 1), bf16x4);
+        const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
+        const int co = ct * TC + i * 32 + 16 * m + 8 * h;
+        if (co < a.Cout) *reinterpret_cast<u32x4*>(a.y + pix[f] * a.ldy + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
   }
 }
@@ -191,18 +218,20 @@ static int db_launch(DbArgs& a, hipStream_t st) {
 
 // x bf16 NHWC [N,H,W,ldx]; om f32 NHWC [N,H,W,ldo]: channels 0..17 = (dy, dx) per tap, 18..26 = mask logits (the raw
 // conv_offset_mask output); wt: [n_ct][9][Cin/64][32*na][64] bf16 rows XOR-swizzled in 16-byte pieces (ops_bf16.py);
-// bias f32 [n_ct*32*na] (BN folded); y bf16 NHWC [N,H,W,ldy]; act 1 = ReLU.  Cin % 64 == 0, Cout % 4 == 0.
+// bias f32 [n_ct*32*na] (BN folded); y bf16 NHWC [N,H,W,ldy]; act 1 = ReLU.  Cin % 64 == 0, Cout % 8 == 0.
 extern "C" int sgta_dcnv2_fwd_bf16(const void* x, int ldx, const float* om, int ldo, const void* wt, long wt_bytes,
                                    const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
                                    int na, int log_tw, int act, hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
-  if (Cin % 64 || Cout % 4 || ldx % 8 || ldy % 4 || ldo < 27 || log_tw < 3 || log_tw > 6) return SGTA_EBADARG;
+  if (Cin % 64 || Cout % 8 || ldx % 8 || ldy % 8 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 27 || log_tw < 3 ||
+      log_tw > 6)
+    return SGTA_EBADARG;
   if (wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
   DbArgs a;
   a.x = reinterpret_cast<const __bf16*>(x); a.ldx = ldx; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
   a.bias = bias; a.y = reinterpret_cast<__bf16*>(y); a.ldy = ldy; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.ngroups = Cin / 64; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act;
-  if (na == 2) return db_launch<2, 2>(a, st);
+  if (na == 2) return db_launch<1, 2>(a, st);
   if (na == 4) return db_launch<1, 4>(a, st);
   return SGTA_EBADARG;
 }

@@ -10,6 +10,7 @@ from . import _lib
 from .ops import ACT_NONE, ACT_RELU, fold_bn, _round_up, _stream  # noqa: F401
 
 OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+FORCE_NPF = None            # tools / tests: force the conv tile size (1: 256 positions, 2: 512)
 BF16 = torch.bfloat16
 
 
@@ -87,9 +88,29 @@ class PackedConvBF16:
         self.bias = bb.float().contiguous()
         self.w_ref = w.to(BF16)                   # tests: the rounded weights, [Cout, Cin, ks, ks]
 
-    def tile_log_tw(self, N, Ho, Wo):
+    def tile_npf(self, N, Ho, Wo):
+        """32-position fragments per wave: 2 (512-position tiles) unless the launch would leave the chip's 256 CUs a short
+        last round (small maps: the tail of a 1.2-round launch costs 40 %); stride 2 is built for 1."""
+        if FORCE_NPF is not None:
+            return 1 if self.stride == 2 else FORCE_NPF
+        if self.ks == 3 and self.stride == 2:
+            return 1
+        n_ct = -(-self.Cout // self.TC)
+
+        def rounds(npf):
+            ltw = self.tile_log_tw(N, Ho, Wo, npf)
+            tw, tr = 1 << ltw, (256 * npf) >> ltw
+            blocks = -(-Wo // tw) * -(-(N * (Ho + 1)) // tr) * n_ct
+            return -(-blocks // 256) * npf, blocks
+        r2, b2 = rounds(2)
+        r1, _ = rounds(1)
+        return 1 if (r1 < r2 and b2 < 4 * 256) else 2
+
+    def tile_log_tw(self, N, Ho, Wo, npf=None):
         """log2 of the tile width that wastes the fewest positions (ties: the wider tile = longer contiguous DMA rows)."""
-        tp = 256 if (self.ks == 3 and self.stride == 2) else 512
+        if npf is None:
+            npf = 1 if (self.ks == 3 and self.stride == 2) else 2
+        tp = 256 * npf
         best = None
         for ltw in (6, 5, 4, 3):
             tw = 1 << ltw
@@ -126,9 +147,10 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cou
         meta = {"kernel": "conv_bf16_kernel<%d,%d,%d>" % (pc.ks, pc.stride, pc.na), "flops": pc.flops(M),
                 "exec_flops": pc.flops(M),
                 "bytes": 2.0 * (pc.Cin * x.N * x.H * x.W + pc.Cout * pc.Cin * pc.ks ** 2) + (2.0 if out_mode == 0 else 4.0) * cout * M}
+    npf = pc.tile_npf(x.N, Ho, Wo)
     _lib.call("sgta_conv_bf16", x.ptr, x.nbytes, x.ld, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
-              rp, ldr, yptr, ldy, x.N, x.H, x.W, pc.Cin, cout, pc.ks, pc.stride, pc.kc, pc.na,
-              pc.tile_log_tw(x.N, Ho, Wo), act, out_mode, nsig, _stream(), meta=meta)
+              rp, ldr, yptr, ldy, x.N, x.H, x.W, pc.Cin, cout, pc.ks, pc.stride, pc.kc, pc.na, npf,
+              pc.tile_log_tw(x.N, Ho, Wo, npf), act, out_mode, nsig, _stream(), meta=meta)
     return out
 
 
@@ -139,8 +161,8 @@ class PackedDCNBF16:
         w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
         co, ci, ks, _ = w.shape
         assert ks == 3
-        if ci % 64 or co % 4:
-            raise _lib.SgtaHipError("bf16 DCN needs Cin %% 64 == 0 and Cout %% 4 == 0, got %d -> %d" % (ci, co))
+        if ci % 64 or co % 8:
+            raise _lib.SgtaHipError("bf16 DCN needs Cin %% 64 == 0 and Cout %% 8 == 0, got %d -> %d" % (ci, co))
         self.Cout, self.Cin = co, ci
         self.na = 2 if co <= 64 else 4
         self.TC = 32 * self.na
@@ -156,7 +178,7 @@ class PackedDCNBF16:
         self.w_ref = w.to(BF16)
 
     def tile_log_tw(self, N, H, W):
-        tp = 512 if self.na == 2 else 256
+        tp = 256                                   # 8 waves x 32 pixels (dcn_bf16.hip)
         best = None
         for ltw in (6, 5, 4, 3):
             tw = 1 << ltw

@@ -67,6 +67,28 @@ def test_conv_bf16(bops, N, cin, cout, H, W, ks, stride, act, res):
     close(nchw(out), ref)
 
 
+@pytest.mark.parametrize("N,cin,cout,H,W,ks", [(3, 128, 256, 30, 40, 3), (2, 64, 64, 17, 23, 3), (2, 448, 128, 15, 20, 1), (1, 16, 16, 40, 72, 3)])
+def test_conv_bf16_half_size_tiles(bops, N, cin, cout, H, W, ks):
+    """The 256-position tiles (npf = 1) the dispatcher picks for small maps give the same result as the 512-position ones."""
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(BF).float()
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (1.5 / (cin * ks * ks) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    pc = bops.PackedConvBF16(w.to(DEV), b.to(DEV))
+    ref = F.relu(F.conv2d(x, pc.w_ref.float().cpu(), b, padding=ks // 2))
+    outs = []
+    for npf in (1, 2):
+        bops.FORCE_NPF = npf
+        try:
+            out = torch.full((N, H, W, cout), 7.0, dtype=BF, device=DEV)
+            bops.conv(bops.ViewH(nhwc(x)), pc, bops.ViewH(out), 1)
+        finally:
+            bops.FORCE_NPF = None
+        close(nchw(out), ref)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_conv_bf16_channel_slices_and_fp32_outputs(bops):
     """Input / output / residual as channel slices of wider buffers (the Root concat buffers), fp32 NHWC output (DCN
     offsets) and fp32 NCHW output with sigmoid on the first channels (heads)."""
