@@ -5,28 +5,42 @@
 // channels, so a lane fetches 8 channels (16 bytes) per corner, blends the four corners in fp32 with its per-(pixel, tap)
 // weights (bilinear weight x validity x sigmoid(mask), computed once per tap from the fp32 offset / mask map) and has
 // the bf16 MFMA B operand of that (pixel, tap, 8 channels) in registers -- the [9*Cin, H*W] column buffer of the
-// reference never exists.  A = the bf16 weights [cout][tap][cin], staged per (tap, 64-channel group) by 16-byte buffer
-// LDS-DMA (double buffered, XOR-swizzled rows), shared by the 8 waves of the work-group; every gathered sample feeds
-// all TC = 64 / 128 output channels of the work-group.  Accumulation fp32 on v_mfma_f32_32x32x16_bf16.
+// reference never exists.  A = the bf16 weights, staged per 16-channel chunk ([tap][TC][16], XOR-swizzled rows) by 16-byte
+// buffer LDS-DMA, shared by the 8 waves of the work-group; every gathered sample feeds all TC = 64 / 128 output
+// channels of the work-group.  Accumulation fp32 on v_mfma_f32_32x32x16_bf16.
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct DbArgs {
-  const __bf16* x;  int ldx;                     // bf16 NHWC input [N,H,W,ldx] (pointer at the view's first channel)
+  const __bf16* x;  int ldx;  long x_bytes;      // bf16 NHWC input [N,H,W,ldx] (pointer at the view's first channel), its extent
   const float* om;  int ldo;                     // f32 NHWC offsets / mask logits [N,H,W,ldo >= 27]
-  const void* wt;   long wt_bytes;               // packed [n_ct][9][Cin/64][TC][64] bf16, swizzled
+  const void* wt;   long wt_bytes;               // packed [n_ct][Cin/16][9][TC][16] bf16, swizzled
   const float* bias;                             // [n_ct * TC]
   __bf16* y;        int ldy;                     // bf16 NHWC output
   int N, H, W, Cin, Cout, ngroups, n_ct, n_rt, n_xt, log_tw, act;
 };
 
-template <int NPF, int NA>
+// Two earlier forms gathered the four corners of every sample straight from global memory (lane = pixel, then 8 lanes per
+// 128-byte line): both ran at ~18 B/clk/CU -- the L2 -> CU fill rate -- because every input pixel is fetched 36 times
+// (9 taps x 4 corners) and the 32 KB L1 cannot hold a tile's neighbourhood.  This form stages the neighbourhood ONCE
+// per 16-channel chunk in LDS (the conv kernel's window machinery: 16-byte buffer LDS-DMA, XOR-swizzled 32-byte rows,
+// double buffered with the chunk's [tap][TC][16] weight image) and gathers from LDS: (TR + 2R + 1) x (TW + 2R + 1) pixels
+// with R = 6, i.e. sampling offsets up to +-6 pixels.  A tap whose sample leaves the window for ANY lane of a wave sends
+// that wave through a slow path for that tap (the four corner runs by buffer loads from global memory) -- a separate
+// code path, selected wave-uniformly, so the compiler never merges LDS and global reads.  Per lane and tap only the window
+// address of the top-left corner and the four weights (bilinear x validity x sigmoid(mask)) stay in registers; they are
+// computed once per tile.
+#define DB_R 6
+
+template <int NA>
 __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
-  constexpr int TC = NA * 32, TP = 256 * NPF, ROWB = 128, SIMG = TC * ROWB, AROUNDS = (SIMG + 8191) / 8192;
-  constexpr int STAGE = AROUNDS * 8192;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int TC = NA * 32, TP = 256, ROWB = 32;
+  constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + 8191) / 8192;
+  constexpr int WROUNDS = 4, WIN_BYTES = WROUNDS * 8192, WS_MAX = WIN_BYTES / ROWB;      // 1024 window slots
+  constexpr int STAGE = WIN_BYTES + AROUNDS * 8192;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   int pt, ct;
   xcd_remap(blockIdx.x, a.n_ct, pt, ct);
@@ -35,137 +49,197 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int TW = 1 << a.log_tw, TR = TP >> a.log_tw;
+  const int WC = TW + 2 * DB_R + 1, WR = TR + 2 * DB_R + 1, WS = WR * WC;
   const int rt = pt / a.n_xt, xt = pt - rt * a.n_xt;
   const int H = a.H, W = a.W;
+  const int R0 = rt * TR - DB_R, X0 = xt * TW - DB_R;                   // stacked row / column of window slot (0, 0)
 
+  // ---- per-lane DMA offsets (chunk-invariant): window slots in stacked-row space (N*H rows), weight image -------------
+  unsigned woff[WROUNDS];
+#pragma unroll
+  for (int t = 0; t < WROUNDS; ++t) {
+    const int pi = t * 512 + tid;
+    const int slot = pi >> 1, pp = pi & 1;
+    unsigned off = 0x80000000u;
+    if (slot < WS) {
+      const int wr = slot / WC, wc = slot - wr * WC;
+      const int Rs = R0 + wr, x = X0 + wc;
+      if (Rs >= 0 && Rs < a.N * H && (unsigned)x < (unsigned)W) {
+        const int piece = pp ^ ((slot >> 3) & 1);
+        off = (unsigned)((((long)Rs * W + x) * a.ldx + piece * 8) * 2);
+      }
+    }
+    woff[t] = off;
+  }
   unsigned aoffw[AROUNDS];
 #pragma unroll
   for (int t = 0; t < AROUNDS; ++t) {
     const int e = (t * 512 + tid) * 16;
-    aoffw[t] = e < SIMG ? (unsigned)e : 0x80000000u;
+    aoffw[t] = e < WIMG ? (unsigned)e : 0x80000000u;
   }
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
   __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), (short)0, (int)a.wt_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
 #endif
-  const int nstages = 9 * a.ngroups;
-  auto stage = [&](int q, int st) {
+  const int nchunks = a.Cin / 16;
+  auto stage = [&](int kc, int st) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned char* adst = smem + st * STAGE + wave * 1024;
+    unsigned char* wdst = smem + st * STAGE + wave * 1024;
+    unsigned char* adst = wdst + WIN_BYTES;
+#pragma unroll
+    for (int t = 0; t < WROUNDS; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * 8192), 16, woff[t], kc * ROWB, 0, 0);
 #pragma unroll
     for (int t = 0; t < AROUNDS; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * 8192), 16, aoffw[t],
-                                               (ct * nstages + q) * SIMG, 0, 0);
+                                               (ct * nchunks + kc) * WIMG, 0, 0);
 #endif
   };
+  stage(0, 0);
 
-  // ---- this lane's pixels ------------------------------------------------------------------------------------
-  int py0[NPF], px0[NPF];
-  long pbase[NPF];                               // image base pixel index n * H * W
-  long pix[NPF];                                 // own pixel index or -1
+  // ---- this lane's pixel and its 9 samples ------------------------------------------------------------------------
+  const int p = wave * 32 + r;
+  const int Rp = rt * TR + (p >> a.log_tw), xp = xt * TW + (p & (TW - 1));
+  const int n = Rp / H, yp = Rp - n * H;
+  const bool okp = n < a.N && xp < W;
+  const long pix = okp ? (long)Rp * W + xp : -1;
+  int sbase[9];                                  // window slot of the sample's top-left corner (y0, x0)
+  float cw[9][4];
+  unsigned inmask = 0;                           // bit t: all four corners of tap t lie inside the staged window
+  {
+    const float* o = a.om + (pix >= 0 ? pix : 0) * a.ldo;
 #pragma unroll
-  for (int f = 0; f < NPF; ++f) {
-    const int i = (wave * NPF + f) * 32 + r;
-    const int R = rt * TR + (i >> a.log_tw), x = xt * TW + (i & (TW - 1));
-    const int n = R / H, y = R - n * H;
-    const bool ok = n < a.N && x < W;
-    py0[f] = y; px0[f] = x;
-    pbase[f] = (long)(ok ? n : 0) * H * W;
-    pix[f] = ok ? pbase[f] + (long)y * W + x : -1;
+    for (int t = 0; t < 9; ++t) {
+      const float dy = o[2 * t], dx = o[2 * t + 1], m = 1.0f / (1.0f + __expf(-o[18 + t]));
+      const float py = (float)(yp - 1 + t / 3) + dy, px = (float)(xp - 1 + t % 3) + dx;
+      const bool inside = okp && py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
+      const float fy = floorf(py), fx = floorf(px);
+      const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const bool oy0 = y0 >= 0, oy1 = y0 + 1 <= H - 1, ox0 = x0 >= 0, ox1 = x0 + 1 <= W - 1;
+      cw[t][0] = (inside && oy0 && ox0) ? hy * hx * m : 0.0f;
+      cw[t][1] = (inside && oy0 && ox1) ? hy * lx * m : 0.0f;
+      cw[t][2] = (inside && oy1 && ox0) ? ly * hx * m : 0.0f;
+      cw[t][3] = (inside && oy1 && ox1) ? ly * lx * m : 0.0f;
+      // window coordinates of (y0, x0); the +1 corners need wr + 1 < WR and wc + 1 < WC.  A sample outside the image has
+      // all-zero weights: it is pointed at slot 0 and counts as inside.
+      const int wr = n * H + y0 - R0, wc = x0 - X0;
+      const bool in = !inside || (wr >= 0 && wr + 1 < WR && wc >= 0 && wc + 1 < WC);
+      sbase[t] = (inside && in) ? wr * WC + wc : 0;
+      inmask |= (in ? 1u : 0u) << t;
+    }
   }
-  unsigned aaddr[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) aaddr[s] = (unsigned)(r * ROWB + (((2 * s + h) ^ ((r >> 1) & 7)) << 4));
+  unsigned aaddr = (unsigned)(r * ROWB + ((h ^ ((r >> 3) & 1)) << 4));
 
-  f32x16 acc[NA][NPF];
+  f32x16 acc[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int f = 0; f < NPF; ++f)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
 
-  // the 27 offset / mask values of this lane's pixels, fetched once (not a dependent load in front of every tap)
-  float omv[NPF][27];
+  auto blend_mma = [&](const bf16x8 (&cv)[4], const float (&w4)[4], const unsigned char* As, int t) {
+    float v[8];
 #pragma unroll
-  for (int f = 0; f < NPF; ++f) {
-    const float* o = a.om + (pix[f] >= 0 ? pix[f] : 0) * a.ldo;
-#pragma unroll
-    for (int j = 0; j < 27; ++j) omv[f][j] = o[j];
-  }
-
-  stage(0, 0);
-  int q = 0;
-#pragma unroll 1
-  for (int t = 0; t < 9; ++t) {
-    // sampling parameters of tap t for this lane's pixels: 4 corner element offsets + 4 weights
-    long coff[NPF][4];
-    float cw[NPF][4];
-#pragma unroll
-    for (int f = 0; f < NPF; ++f) {
-      float dy = 0.0f, dx = 0.0f, ml = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 9; ++j)                     // register array indexed by the (runtime) tap: select chain
-        if (j == t) { dy = omv[f][2 * j]; dx = omv[f][2 * j + 1]; ml = omv[f][18 + j]; }
-      const float m = 1.0f / (1.0f + __expf(-ml));
-      const float py = (float)(py0[f] - 1 + t / 3) + dy, px = (float)(px0[f] - 1 + t % 3) + dx;
-      const bool inside = pix[f] >= 0 && py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
-      const float fy = floorf(py), fx = floorf(px);
-      const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
-      const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
-      const bool oy0 = y0 >= 0, oy1 = y1 <= H - 1, ox0 = x0 >= 0, ox1 = x1 <= W - 1;
-      const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
-      const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
-      coff[f][0] = (pbase[f] + (long)cy0 * W + cx0) * a.ldx;
-      coff[f][1] = (pbase[f] + (long)cy0 * W + cx1) * a.ldx;
-      coff[f][2] = (pbase[f] + (long)cy1 * W + cx0) * a.ldx;
-      coff[f][3] = (pbase[f] + (long)cy1 * W + cx1) * a.ldx;
-      cw[f][0] = (inside && oy0 && ox0) ? hy * hx * m : 0.0f;
-      cw[f][1] = (inside && oy0 && ox1) ? hy * lx * m : 0.0f;
-      cw[f][2] = (inside && oy1 && ox0) ? ly * hx * m : 0.0f;
-      cw[f][3] = (inside && oy1 && ox1) ? ly * lx * m : 0.0f;
+    for (int j = 0; j < 8; ++j) {
+      float s0 = w4[0] * (float)cv[0][j];
+      s0 = __builtin_fmaf(w4[1], (float)cv[1][j], s0);
+      s0 = __builtin_fmaf(w4[2], (float)cv[2][j], s0);
+      v[j] = __builtin_fmaf(w4[3], (float)cv[3][j], s0);
     }
-#pragma unroll 1
-    for (int g = 0; g < a.ngroups; ++g, ++q) {
-      const int st = q & 1;
-      // all 16 corner runs of this 64-channel group in flight together (the blend of k-step s waits only for its own)
-      bf16x8 cv[4][NPF][4];
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    const bf16x8 bfr = __builtin_convertvector(vv, bf16x8);
+    bf16x8 af[NA];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
 #pragma unroll
-        for (int f = 0; f < NPF; ++f)
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            cv[s][f][k] = *reinterpret_cast<const bf16x8*>(a.x + coff[f][k] + g * 64 + s * 16 + h * 8);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * NPF) : "memory");          // the weight DMA of this stage (older than the loads)
+    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
+  };
+
+  // wave-uniform choice for the whole tile: every sample of every lane inside the staged window -> LDS gathers; otherwise
+  // this wave fetches its corner runs from global memory (rare: offsets beyond +-6 pixels).  Two separate loops with the
+  // same barrier structure, so LDS and global reads never share a code path.
+  const bool all_in = __builtin_amdgcn_ballot_w64(inmask != 0x1ffu) == 0;
+  if (all_in) {
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int st = kc & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (q + 1 < nstages) stage(q + 1, st ^ 1);
-      const unsigned char* As = smem + st * STAGE;
+      if (kc + 1 < nchunks) stage(kc + 1, st ^ 1);
+      const unsigned char* Ws = smem + st * STAGE;
+      const unsigned char* As = Ws + WIN_BYTES;
+      // software pipeline over the taps: the four corner reads of tap t + 1 and the weight fragments of tap t are issued
+      // BEFORE the blend of tap t, whose ~100 VALU instructions then cover their LDS latency (in-order returns: the
+      // compiler's counted lgkmcnt waits let the older reads be consumed while the younger ones are in flight)
+      auto corners = [&](int t, bf16x8 (&cv)[4]) {
+        int sb = sbase[t];
+        asm volatile("" : "+v"(sb));                 // opaque: keeps the 36 corner addresses out of registers (recomputed per chunk)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bf16x8 bfr[NPF];
-#pragma unroll
-        for (int f = 0; f < NPF; ++f) {
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float s0 = cw[f][0] * (float)cv[s][f][0][j];
-            s0 = __builtin_fmaf(cw[f][1], (float)cv[s][f][1][j], s0);
-            s0 = __builtin_fmaf(cw[f][2], (float)cv[s][f][2][j], s0);
-            v[j] = __builtin_fmaf(cw[f][3], (float)cv[s][f][3][j], s0);
-          }
-          typedef float f32x8 __attribute__((ext_vector_type(8)));
-          const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-          bfr[f] = __builtin_convertvector(vv, bf16x8);
+        for (int k = 0; k < 4; ++k) {
+          const int slot = sb + (k & 1) + (k >> 1) * WC;
+          cv[k] = *reinterpret_cast<const bf16x8*>(Ws + slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
         }
+      };
+      bf16x8 cva[4], cvb[4];
+      corners(0, cva);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        bf16x8 (&cur)[4] = (t & 1) ? cvb : cva;
+        bf16x8 (&nxt)[4] = (t & 1) ? cva : cvb;
+        if (t + 1 < 9) corners(t + 1, nxt);
         bf16x8 af[NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + i * 32 * ROWB + aaddr[s]);
+        for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
+        __builtin_amdgcn_sched_barrier(0);           // the reads above stay above the blend below
+        float v[8];
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
+        for (int j = 0; j < 8; ++j) {
+          float s0 = cw[t][0] * (float)cur[0][j];
+          s0 = __builtin_fmaf(cw[t][1], (float)cur[1][j], s0);
+          s0 = __builtin_fmaf(cw[t][2], (float)cur[2][j], s0);
+          v[j] = __builtin_fmaf(cw[t][3], (float)cur[3][j], s0);
+        }
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+        const bf16x8 bfr = __builtin_convertvector(vv, bf16x8);
 #pragma unroll
-          for (int f = 0; f < NPF; ++f)
-            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[f], acc[i][f], 0, 0, 0);
+        for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    const float* o = a.om + (pix >= 0 ? pix : 0) * a.ldo;
+    const int nb = (okp ? n : 0) * H;
+    for (int kc = 0; kc < nchunks; ++kc) {
+      const int st = kc & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kc + 1 < nchunks) stage(kc + 1, st ^ 1);
+      const unsigned char* As = smem + st * STAGE + WIN_BYTES;
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        const float py = (float)(yp - 1 + t / 3) + o[2 * t], px = (float)(xp - 1 + t % 3) + o[2 * t + 1];
+        const float m = 1.0f / (1.0f + __expf(-o[18 + t]));
+        const bool inside = okp && py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
+        const float fy = floorf(py), fx = floorf(px);
+        const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const bool oy0 = y0 >= 0, oy1 = y0 + 1 <= H - 1, ox0 = x0 >= 0, ox1 = x0 + 1 <= W - 1;
+        const float w4[4] = {(inside && oy0 && ox0) ? hy * hx * m : 0.0f, (inside && oy0 && ox1) ? hy * lx * m : 0.0f,
+                             (inside && oy1 && ox0) ? ly * hx * m : 0.0f, (inside && oy1 && ox1) ? ly * lx * m : 0.0f};
+        const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
+        const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x0 + 1, 0), W - 1);
+        bf16x8 cv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int yy = (k >> 1) ? cy1 : cy0, xx = (k & 1) ? cx1 : cx0;
+          const unsigned off = (unsigned)((((long)(nb + yy) * W + xx) * a.ldx + h * 8) * 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+          cv[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, kc * ROWB, 0));
+#endif
+        }
+        blend_mma(cv, w4, As, t);
       }
     }
   }
@@ -174,64 +248,76 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
   // consecutive channels (16 bytes) and a pixel's two lanes 32 contiguous bytes (see conv_bf16.hip)
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  auto value4 = [&](int i, int f, int g4) {
+  auto value4 = [&](int i, int g4) {
     const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (co0 < a.Cout) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = acc[i][f][4 * g4 + j] + bv[j];
+        v[j] = acc[i][4 * g4 + j] + bv[j];
         if (a.act == 1) v[j] = fmaxf(v[j], 0.0f);
       }
     }
     return v;
   };
-#pragma unroll
-  for (int f = 0; f < NPF; ++f) {
-    if (pix[f] < 0) continue;
+  if (pix >= 0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const bf16x4 pb = __builtin_convertvector(value4(i, f, 2 * m), bf16x4);
-        const bf16x4 qb = __builtin_convertvector(value4(i, f, 2 * m + 1), bf16x4);
+        const bf16x4 pb = __builtin_convertvector(value4(i, 2 * m), bf16x4);
+        const bf16x4 qb = __builtin_convertvector(value4(i, 2 * m + 1), bf16x4);
         const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
         const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
         const int co = ct * TC + i * 32 + 16 * m + 8 * h;
-        if (co < a.Cout) *reinterpret_cast<u32x4*>(a.y + pix[f] * a.ldy + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        if (co < a.Cout) *reinterpret_cast<u32x4*>(a.y + pix * a.ldy + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
   }
 }
 
-template <int NPF, int NA>
+template <int NA>
 static int db_launch(DbArgs& a, hipStream_t st) {
-  const int TP = 256 * NPF, TW = 1 << a.log_tw, TR = TP >> a.log_tw;
+  constexpr int WIMG = 9 * NA * 32 * 32;
+  constexpr int LDS = 2 * (4 * 8192 + ((WIMG + 8191) / 8192) * 8192);
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = dcn_bf16_kernel<NA>;
+  static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
+  bool& done = attr_by_dev[sgta_device_slot()];
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return SGTA_EBADARG;
+    done = true;
+  }
+  const int TW = 1 << a.log_tw, TR = 256 >> a.log_tw;
+  if ((TR + 2 * DB_R + 1) * (TW + 2 * DB_R + 1) > 1024) return SGTA_EBADARG;     // window slots (log_tw 3..5)
   a.n_rt = cdiv((long)a.N * a.H, TR);
   a.n_xt = cdiv(a.W, TW);
   const int grid = cdiv(a.n_rt * a.n_xt, 8) * 8 * a.n_ct;
-  hipLaunchKernelGGL((dcn_bf16_kernel<NPF, NA>), dim3(grid), dim3(512), 0, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
 
 // x bf16 NHWC [N,H,W,ldx]; om f32 NHWC [N,H,W,ldo]: channels 0..17 = (dy, dx) per tap, 18..26 = mask logits (the raw
-// conv_offset_mask output); wt: [n_ct][9][Cin/64][32*na][64] bf16 rows XOR-swizzled in 16-byte pieces (ops_bf16.py);
-// bias f32 [n_ct*32*na] (BN folded); y bf16 NHWC [N,H,W,ldy]; act 1 = ReLU.  Cin % 64 == 0, Cout % 8 == 0.
+// conv_offset_mask output); wt: [n_ct][Cin/16][9][32*na][16] bf16 rows XOR-swizzled in 16-byte pieces (the 3x3 layout of
+// sgta_conv_bf16, ops_bf16.py); bias f32 [n_ct*32*na] (BN folded); y bf16 NHWC [N,H,W,ldy]; act 1 = ReLU.
+// Cin % 16 == 0, Cout % 8 == 0, log_tw in 3..5.
 extern "C" int sgta_dcnv2_fwd_bf16(const void* x, int ldx, const float* om, int ldo, const void* wt, long wt_bytes,
                                    const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
                                    int na, int log_tw, int act, hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
-  if (Cin % 64 || Cout % 8 || ldx % 8 || ldy % 8 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 27 || log_tw < 3 ||
-      log_tw > 6)
+  if (Cin % 16 || Cout % 8 || ldx % 8 || ldy % 8 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 27 || log_tw < 3 ||
+      log_tw > 5)
     return SGTA_EBADARG;
   if (wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
+  if ((long)N * H * W * ldx * 2 > 0x7fffffffL) return SGTA_EBADARG;      // 31-bit byte offsets in the gather
   DbArgs a;
-  a.x = reinterpret_cast<const __bf16*>(x); a.ldx = ldx; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
+  a.x = reinterpret_cast<const __bf16*>(x); a.ldx = ldx; a.x_bytes = ((long)N * H * W - 1) * ldx * 2 + (long)Cin * 2; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
   a.bias = bias; a.y = reinterpret_cast<__bf16*>(y); a.ldy = ldy; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-  a.ngroups = Cin / 64; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act;
-  if (na == 2) return db_launch<1, 2>(a, st);
-  if (na == 4) return db_launch<1, 4>(a, st);
+  a.ngroups = Cin / 16; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act;
+  if (na == 2) return db_launch<2>(a, st);
+  if (na == 4) return db_launch<4>(a, st);
   return SGTA_EBADARG;
 }

@@ -155,32 +155,33 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cou
 
 
 class PackedDCNBF16:
-    """bf16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][tap][Cin/64][TC][64], BN folded."""
+    """bf16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][Cin/16][tap][TC][16] (the 3x3
+    layout of sgta_conv_bf16), BN folded."""
 
     def __init__(self, weight, bias=None, bn=None):
         w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
         co, ci, ks, _ = w.shape
         assert ks == 3
-        if ci % 64 or co % 8:
-            raise _lib.SgtaHipError("bf16 DCN needs Cin %% 64 == 0 and Cout %% 8 == 0, got %d -> %d" % (ci, co))
+        if ci % 16 or co % 8:
+            raise _lib.SgtaHipError("bf16 DCN needs Cin %% 16 == 0 and Cout %% 8 == 0, got %d -> %d" % (ci, co))
         self.Cout, self.Cin = co, ci
         self.na = 2 if co <= 64 else 4
         self.TC = 32 * self.na
         n_ct = -(-co // self.TC)
-        ng = ci // 64
+        nch = ci // 16
         wp = w.new_zeros(n_ct * self.TC, ci, 9)
         wp[:co] = w.reshape(co, ci, 9)
-        img = wp.view(n_ct, self.TC, ng, 64, 9).permute(0, 4, 2, 1, 3).contiguous()       # [ct][tap][group][TC][64]
-        self.wt = _swizzle_rows(img, 64).to(BF16).contiguous()
+        img = wp.view(n_ct, self.TC, nch, 16, 9).permute(0, 2, 4, 1, 3).contiguous()      # [ct][chunk][tap][TC][16]
+        self.wt = _swizzle_rows(img, 16).to(BF16).contiguous()
         bb = b.new_zeros(n_ct * self.TC)
         bb[:co] = b
         self.bias = bb.float().contiguous()
         self.w_ref = w.to(BF16)
 
     def tile_log_tw(self, N, H, W):
-        tp = 256                                   # 8 waves x 32 pixels (dcn_bf16.hip)
+        tp = 256                                   # 8 waves x 32 pixels (dcn_bf16.hip); window of <= 1024 slots: TW <= 32
         best = None
-        for ltw in (6, 5, 4, 3):
+        for ltw in (5, 4, 3):
             tw = 1 << ltw
             tr = tp // tw
             work = (-(-W // tw) * tw) * (-(-(N * H) // tr) * tr)
