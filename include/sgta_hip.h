@@ -335,7 +335,10 @@ int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt
  * ``sgta_dcnv2_fwd_bf16`` of SURVEY.md section 8b.  om: f32 NHWC [N,H,W,ldo], channels 0..17 = (dy, dx) per tap,
  * 18..26 = mask logits (raw conv_offset_mask output, sigmoid applied here); sampling coordinates and bilinear /
  * mask weights in fp32, the gathered corners are bf16 (16-byte channel runs), blend in fp32, product on bf16 MFMA.
- * wt: [Cout tile][9][Cin/64][32*na][64] bf16 swizzled; Cin % 64 == 0; na in {2,4}. */
+ * ldo >= 28 and ldo % 4 == 0 (a pixel's 27 values are fetched as 7 x 16 bytes).  The sampling neighbourhood of a tile is
+ * staged in LDS (offsets up to +-6 pixels; beyond that a wave falls back to gathers from global memory, same arithmetic),
+ * converted once per 16-channel chunk to fp16 and blended by v_fma_mix_f32.
+ * wt: [Cout tile][Cin/16][9][32*na][16] bf16 swizzled (the 3x3 layout of sgta_conv_bf16); Cin % 16 == 0; na in {2,4}; log_tw 3..5. */
 int sgta_dcnv2_fwd_bf16(const void* x, int ldx, const float* om, int ldo, const void* wt, long wt_bytes,
                         const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
                         int na, int log_tw, int act, sgta_stream_t stream);

@@ -12,15 +12,20 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct DbArgs {
   const __bf16* x;  int ldx;  long x_bytes;      // bf16 NHWC input [N,H,W,ldx] (pointer at the view's first channel), its extent
-  const float* om;  int ldo;                     // f32 NHWC offsets / mask logits [N,H,W,ldo >= 27]
+  const float* om;  int ldo;                     // f32 NHWC offsets / mask logits [N,H,W,ldo]: ldo >= 28, ldo % 4 == 0 (read as 7 x 16 bytes)
   const void* wt;   long wt_bytes;               // packed [n_ct][Cin/16][9][TC][16] bf16, swizzled
   const float* bias;                             // [n_ct * TC]
   __bf16* y;        int ldy;                     // bf16 NHWC output
   int N, H, W, Cin, Cout, ngroups, n_ct, n_rt, n_xt, log_tw, act;
+  unsigned mH, mWC[3];                           // ceil(2^32 / H), ceil(2^32 / window columns) for log_tw 3..5 (umulhi division)
 };
+
+// floor(v / d) for 0 <= v < 2^16 through the launcher's m = ceil(2^32 / d): no integer-division sequence in the prologue
+__device__ __forceinline__ int db_div(int v, unsigned m) { return (int)__umulhi((unsigned)v, m); }
 
 // Two earlier forms gathered the four corners of every sample straight from global memory (lane = pixel, then 8 lanes per
 // 128-byte line): both ran at ~18 B/clk/CU -- the L2 -> CU fill rate -- because every input pixel is fetched 36 times
@@ -32,14 +37,27 @@ struct DbArgs {
 // code path, selected wave-uniformly, so the compiler never merges LDS and global reads.  Per lane and tap only the window
 // address of the top-left corner and the four weights (bilinear x validity x sigmoid(mask)) stay in registers; they are
 // computed once per tile.
+// VALU issue (one wave64 instruction per ~4 cycles and SIMD) is what bounds the gather: 96 instructions per wave, tap and 8
+// channels, a third of them bf16 -> f32 conversions of window elements that are each used ~36 times.  So the staged
+// window is converted ONCE per chunk, in place, to fp16 (exact for bf16 values with |x| in [6e-5, 65504]; larger values
+// are clamped to +-65504, smaller ones flush towards zero) and the blend is four v_fma_mix_f32 per channel (fp32
+// weight x fp16 corner + fp32 sum, the fp16 -> fp32 widening inside the instruction): 32 + 4 (pack) instead of 68.
 #define DB_R 6
+#ifndef DB_ABLATE
+#define DB_ABLATE 0          // tools only (tools/dcn_ablate.sh): 1 no MFMA, 2 no blend, 3 no corner reads, 4 no conversion, 5 no DMA
+#endif
 
+// Work-group shape: 256 threads = 4 waves x 32 pixels, SINGLE-buffered LDS (window 24 KB + weights 20 / 36 KB), so that two
+// to three work-groups share a CU and one's prologue (27 offset loads, 9 x sampling parameters), DMA waits and epilogue
+// run under the others' gather -- with one 8-wave double-buffered work-group per CU those phases were 45 % of a
+// 64-channel layer's time (25 k cycles per work-group against 7.5 k per chunk).
 template <int NA>
-__global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
-  constexpr int TC = NA * 32, TP = 256, ROWB = 32;
-  constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + 8191) / 8192;
-  constexpr int WROUNDS = 4, WIN_BYTES = WROUNDS * 8192, WS_MAX = WIN_BYTES / ROWB;      // 1024 window slots
-  constexpr int STAGE = WIN_BYTES + AROUNDS * 8192;
+__global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
+  constexpr int TC = NA * 32, TP = 128, ROWB = 32, NT = 256;
+  constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + NT * 16 - 1) / (NT * 16);
+  constexpr int WS_MAX = (4 + 2 * DB_R + 1) * (32 + 2 * DB_R + 1);      // 4 x 32 tiles have the largest window (765 slots)
+  constexpr int WROUNDS = (WS_MAX * 2 + NT - 1) / NT, WIN_BYTES = WROUNDS * NT * 16;
+  constexpr int STAGE = WIN_BYTES + AROUNDS * NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   int pt, ct;
@@ -50,19 +68,20 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
   const int r = lane & 31, h = lane >> 5;
   const int TW = 1 << a.log_tw, TR = TP >> a.log_tw;
   const int WC = TW + 2 * DB_R + 1, WR = TR + 2 * DB_R + 1, WS = WR * WC;
-  const int rt = pt / a.n_xt, xt = pt - rt * a.n_xt;
+  const int rt = pt / a.n_xt, xt = pt - rt * a.n_xt;                    // (scalar division: once per work-group)
   const int H = a.H, W = a.W;
   const int R0 = rt * TR - DB_R, X0 = xt * TW - DB_R;                   // stacked row / column of window slot (0, 0)
+  const unsigned mwc = a.mWC[a.log_tw - 3];
 
   // ---- per-lane DMA offsets (chunk-invariant): window slots in stacked-row space (N*H rows), weight image -------------
   unsigned woff[WROUNDS];
 #pragma unroll
   for (int t = 0; t < WROUNDS; ++t) {
-    const int pi = t * 512 + tid;
+    const int pi = t * NT + tid;
     const int slot = pi >> 1, pp = pi & 1;
     unsigned off = 0x80000000u;
     if (slot < WS) {
-      const int wr = slot / WC, wc = slot - wr * WC;
+      const int wr = db_div(slot, mwc), wc = slot - wr * WC;
       const int Rs = R0 + wr, x = X0 + wc;
       if (Rs >= 0 && Rs < a.N * H && (unsigned)x < (unsigned)W) {
         const int piece = pp ^ ((slot >> 3) & 1);
@@ -74,7 +93,7 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
   unsigned aoffw[AROUNDS];
 #pragma unroll
   for (int t = 0; t < AROUNDS; ++t) {
-    const int e = (t * 512 + tid) * 16;
+    const int e = (t * NT + tid) * 16;
     aoffw[t] = e < WIMG ? (unsigned)e : 0x80000000u;
   }
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -83,35 +102,44 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
   __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
 #endif
   const int nchunks = a.Cin / 16;
-  auto stage = [&](int kc, int st) {
+  auto stage = [&](int kc) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned char* wdst = smem + st * STAGE + wave * 1024;
+    unsigned char* wdst = smem + wave * 1024;
     unsigned char* adst = wdst + WIN_BYTES;
 #pragma unroll
     for (int t = 0; t < WROUNDS; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * 8192), 16, woff[t], kc * ROWB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * NT * 16), 16, woff[t], kc * ROWB, 0, 0);
 #pragma unroll
     for (int t = 0; t < AROUNDS; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * 8192), 16, aoffw[t],
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * NT * 16), 16, aoffw[t],
                                                (ct * nchunks + kc) * WIMG, 0, 0);
 #endif
   };
-  stage(0, 0);
+  stage(0);
 
   // ---- this lane's pixel and its 9 samples ------------------------------------------------------------------------
   const int p = wave * 32 + r;
   const int Rp = rt * TR + (p >> a.log_tw), xp = xt * TW + (p & (TW - 1));
-  const int n = Rp / H, yp = Rp - n * H;
+  const int n = db_div(Rp, a.mH), yp = Rp - n * H;
   const bool okp = n < a.N && xp < W;
   const long pix = okp ? (long)Rp * W + xp : -1;
+  constexpr bool PRE = NA <= 2;                  // registers allow keeping all 36 corner LDS addresses (else 9 slots + on-the-fly)
   int sbase[9];                                  // window slot of the sample's top-left corner (y0, x0)
+  unsigned caddr[PRE ? 9 : 1][4];
   float cw[9][4];
   unsigned inmask = 0;                           // bit t: all four corners of tap t lie inside the staged window
   {
-    const float* o = a.om + (pix >= 0 ? pix : 0) * a.ldo;
+    // the pixel's 27 offset / mask values: one 128-byte row, fetched as 7 x 16 bytes
+    const f32x4* o4 = reinterpret_cast<const f32x4*>(a.om + (pix >= 0 ? pix : 0) * a.ldo);
+    float o[28];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const f32x4 v4 = o4[q];
+      o[4 * q] = v4[0]; o[4 * q + 1] = v4[1]; o[4 * q + 2] = v4[2]; o[4 * q + 3] = v4[3];
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float dy = o[2 * t], dx = o[2 * t + 1], m = 1.0f / (1.0f + __expf(-o[18 + t]));
+      const float dy = o[2 * t], dx = o[2 * t + 1], m = __builtin_amdgcn_rcpf(1.0f + __expf(-o[18 + t]));
       const float py = (float)(yp - 1 + t / 3) + dy, px = (float)(xp - 1 + t % 3) + dx;
       const bool inside = okp && py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
       const float fy = floorf(py), fx = floorf(px);
@@ -127,16 +155,28 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
       const int wr = n * H + y0 - R0, wc = x0 - X0;
       const bool in = !inside || (wr >= 0 && wr + 1 < WR && wc >= 0 && wc + 1 < WC);
       sbase[t] = (inside && in) ? wr * WC + wc : 0;
+      if (PRE) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int slot = sbase[t] + (k & 1) + (k >> 1) * WC;
+          caddr[PRE ? t : 0][k] = (unsigned)(slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
+        }
+      }
       inmask |= (in ? 1u : 0u) << t;
     }
   }
   unsigned aaddr = (unsigned)(r * ROWB + ((h ^ ((r >> 3) & 1)) << 4));
 
+  // the accumulators start at the bias (C/D row = (q & 3) + 8 (q >> 2) + 4 h): no dependent bias loads in the epilogue
   f32x16 acc[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + ct * TC + i * 32 + 8 * g4 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][4 * g4 + j] = bv[j];
+    }
 
   auto blend_mma = [&](const bf16x8 (&cv)[4], const float (&w4)[4], const unsigned char* As, int t) {
     float v[8];
@@ -161,66 +201,86 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
   // this wave fetches its corner runs from global memory (rare: offsets beyond +-6 pixels).  Two separate loops with the
   // same barrier structure, so LDS and global reads never share a code path.
   const bool all_in = __builtin_amdgcn_ballot_w64(inmask != 0x1ffu) == 0;
+  // in-place bf16 -> fp16 conversion of this thread's OWN window pieces (the ones its DMA lanes wrote): every wave runs it,
+  // also the waves on the slow path (they read nothing from the window but share the barriers)
+  auto convert_window = [&](unsigned char* Wbuf) {
+#pragma unroll
+    for (int t = 0; t < WROUNDS; ++t) {
+      unsigned char* pp = Wbuf + (t * NT + tid) * 16;
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(pp);
+      f16x8 hv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)fminf(fmaxf((float)b[j], -65504.0f), 65504.0f);
+      *reinterpret_cast<f16x8*>(pp) = hv;
+    }
+  };
+  unsigned char* const Ws = smem;
+  const unsigned char* const As = smem + WIN_BYTES;
   if (all_in) {
-    for (int kc = 0; kc < nchunks; ++kc) {
-      const int st = kc & 1;
+    for (int kc = 0; kc < (DB_ABLATE == 6 ? 0 : (DB_ABLATE == 7 ? 1 : nchunks)); ++kc) {
+      if (kc) {
+        __builtin_amdgcn_s_barrier();              // every wave is done with chunk kc - 1: the buffers may be overwritten
+        if (DB_ABLATE != 5) stage(kc);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (kc + 1 < nchunks) stage(kc + 1, st ^ 1);
-      const unsigned char* Ws = smem + st * STAGE;
-      const unsigned char* As = Ws + WIN_BYTES;
-      // software pipeline over the taps: the four corner reads of tap t + 1 and the weight fragments of tap t are issued
-      // BEFORE the blend of tap t, whose ~100 VALU instructions then cover their LDS latency (in-order returns: the
-      // compiler's counted lgkmcnt waits let the older reads be consumed while the younger ones are in flight)
-      auto corners = [&](int t, bf16x8 (&cv)[4]) {
+      if (DB_ABLATE != 4) convert_window(Ws);      // own pieces only: no barrier needed between the DMA wait and this
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                // window (converted) + weights of chunk kc complete for all waves
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        f16x8 cv[4];
         int sb = sbase[t];
-        asm volatile("" : "+v"(sb));                 // opaque: keeps the 36 corner addresses out of registers (recomputed per chunk)
+        if (!PRE) asm volatile("" : "+v"(sb));       // opaque: the corner addresses are recomputed per chunk, not kept in registers
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int slot = sb + (k & 1) + (k >> 1) * WC;
-          cv[k] = *reinterpret_cast<const bf16x8*>(Ws + slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
+          if (PRE) {
+            cv[k] = *reinterpret_cast<const f16x8*>(Ws + caddr[PRE ? t : 0][k]);
+          } else if (DB_ABLATE == 3) {
+            const _Float16 cst = (_Float16)(float)(slot & 7);
+            cv[k] = f16x8{cst, cst, cst, cst, cst, cst, cst, cst};
+          } else {
+            cv[k] = *reinterpret_cast<const f16x8*>(Ws + slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
+          }
         }
-      };
-      bf16x8 cva[4], cvb[4];
-      corners(0, cva);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        bf16x8 (&cur)[4] = (t & 1) ? cvb : cva;
-        bf16x8 (&nxt)[4] = (t & 1) ? cva : cvb;
-        if (t + 1 < 9) corners(t + 1, nxt);
         bf16x8 af[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
-        __builtin_amdgcn_sched_barrier(0);           // the reads above stay above the blend below
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float s0 = cw[t][0] * (float)cur[0][j];
-          s0 = __builtin_fmaf(cw[t][1], (float)cur[1][j], s0);
-          s0 = __builtin_fmaf(cw[t][2], (float)cur[2][j], s0);
-          v[j] = __builtin_fmaf(cw[t][3], (float)cur[3][j], s0);
+        for (int j = 0; j < 8; ++j) {                // four v_fma_mix_f32: fp32 weight x fp16 corner + fp32 sum
+          float s0 = __builtin_fmaf(cw[t][0], (float)cv[0][j], 0.0f);
+          s0 = __builtin_fmaf(cw[t][1], (float)cv[1][j], s0);
+          s0 = __builtin_fmaf(cw[t][2], (float)cv[2][j], s0);
+          v[j] = __builtin_fmaf(cw[t][3], (float)cv[3][j], s0);
         }
         typedef float f32x8 __attribute__((ext_vector_type(8)));
         const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-        const bf16x8 bfr = __builtin_convertvector(vv, bf16x8);
+        const bf16x8 bfr = DB_ABLATE == 2 ? __builtin_bit_cast(bf16x8, cv[0]) : __builtin_convertvector(vv, bf16x8);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NA; ++i) {
+          if (DB_ABLATE == 1) acc[i][t] += (float)bfr[i] + (float)af[i][t & 7];
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);           // one tap's reads in flight at a time (registers: 3 work-groups per CU)
       }
     }
   } else {
     const float* o = a.om + (pix >= 0 ? pix : 0) * a.ldo;
     const int nb = (okp ? n : 0) * H;
     for (int kc = 0; kc < nchunks; ++kc) {
-      const int st = kc & 1;
+      if (kc) {
+        __builtin_amdgcn_s_barrier();
+        stage(kc);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      convert_window(Ws);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (kc + 1 < nchunks) stage(kc + 1, st ^ 1);
-      const unsigned char* As = smem + st * STAGE + WIN_BYTES;
 #pragma unroll 1
       for (int t = 0; t < 9; ++t) {
         const float py = (float)(yp - 1 + t / 3) + o[2 * t], px = (float)(xp - 1 + t % 3) + o[2 * t + 1];
-        const float m = 1.0f / (1.0f + __expf(-o[18 + t]));
+        const float m = __builtin_amdgcn_rcpf(1.0f + __expf(-o[18 + t]));
         const bool inside = okp && py > -1.0f && px > -1.0f && py < (float)H && px < (float)W;
         const float fy = floorf(py), fx = floorf(px);
         const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
@@ -252,10 +312,9 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
     const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (co0 < a.Cout) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        v[j] = acc[i][4 * g4 + j] + bv[j];
+        v[j] = acc[i][4 * g4 + j];
         if (a.act == 1) v[j] = fmaxf(v[j], 0.0f);
       }
     }
@@ -279,23 +338,17 @@ __global__ __launch_bounds__(512) void dcn_bf16_kernel(DbArgs a) {
 
 template <int NA>
 static int db_launch(DbArgs& a, hipStream_t st) {
-  constexpr int WIMG = 9 * NA * 32 * 32;
-  constexpr int LDS = 2 * (4 * 8192 + ((WIMG + 8191) / 8192) * 8192);
-  static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = dcn_bf16_kernel<NA>;
-  static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
-  bool& done = attr_by_dev[sgta_device_slot()];
-  if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return SGTA_EBADARG;
-    done = true;
-  }
-  const int TW = 1 << a.log_tw, TR = 256 >> a.log_tw;
-  if ((TR + 2 * DB_R + 1) * (TW + 2 * DB_R + 1) > 1024) return SGTA_EBADARG;     // window slots (log_tw 3..5)
+  constexpr int NT = 256, WIMG = 9 * NA * 32 * 32, WS_MAX = (4 + 2 * DB_R + 1) * (32 + 2 * DB_R + 1);
+  constexpr int LDS = ((WS_MAX * 2 + NT - 1) / NT + (WIMG + NT * 16 - 1) / (NT * 16)) * NT * 16;
+  static_assert(LDS <= 64 * 1024, "two or three work-groups per CU");
+  const int TW = 1 << a.log_tw, TR = 128 >> a.log_tw;
+  a.mH = (unsigned)((0x100000000ULL + a.H - 1) / a.H);
+  for (int l = 3; l <= 5; ++l) a.mWC[l - 3] = (unsigned)((0x100000000ULL + (1 << l) + 2 * DB_R) / ((1 << l) + 2 * DB_R + 1));
+  if ((long)a.N * a.H >= 65536 || a.H < 2) return SGTA_EBADARG;          // umulhi division range
   a.n_rt = cdiv((long)a.N * a.H, TR);
   a.n_xt = cdiv(a.W, TW);
   const int grid = cdiv(a.n_rt * a.n_xt, 8) * 8 * a.n_ct;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a);
+  hipLaunchKernelGGL((dcn_bf16_kernel<NA>), dim3(grid), dim3(NT), LDS, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
@@ -308,7 +361,7 @@ extern "C" int sgta_dcnv2_fwd_bf16(const void* x, int ldx, const float* om, int 
                                    const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
                                    int na, int log_tw, int act, hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
-  if (Cin % 16 || Cout % 8 || ldx % 8 || ldy % 8 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 27 || log_tw < 3 ||
+  if (Cin % 16 || Cout % 8 || ldx % 8 || ldy % 8 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 28 || ldo % 4 || ((uintptr_t)om & 15) || log_tw < 3 ||
       log_tw > 5)
     return SGTA_EBADARG;
   if (wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;

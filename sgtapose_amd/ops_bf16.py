@@ -179,7 +179,7 @@ class PackedDCNBF16:
         self.w_ref = w.to(BF16)
 
     def tile_log_tw(self, N, H, W):
-        tp = 256                                   # 8 waves x 32 pixels (dcn_bf16.hip); window of <= 1024 slots: TW <= 32
+        tp = 128                                   # 4 waves x 32 pixels (dcn_bf16.hip); window of <= 765 slots: TW <= 32
         best = None
         for ltw in (5, 4, 3):
             tw = 1 << ltw

@@ -7,6 +7,9 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
+from sgtapose_amd import _lib  # noqa: E402
+if os.environ.get("SGTA_LIB"):                 # ablation builds (tools/dcn_ablate.sh)
+    _lib.LIB_PATH = os.environ["SGTA_LIB"]
 from sgtapose_amd import ops_bf16 as bops  # noqa: E402
 
 DEV = "cuda:0"
