@@ -258,3 +258,45 @@ def test_bf16_detector_keypoints_on_peaked_weights():
     if same.any():
         l2 = np.sqrt(((dets["cts_wreg"].cpu().numpy() - ref_dets["cts_wreg"])[same] ** 2).sum(1)).max()
         assert l2 < 0.1, l2
+
+
+def test_bf16_benched_configuration_matches_fp32_oracle():
+    """BASELINE configs[2]'s per-GPU shard AT ITS BENCHED SIZE (B = 32, 480x640): first / middle / last samples of the
+    bf16 batch against the fp32 oracle on those samples, with the stated bf16 tolerance."""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _bf16_model()
+    inp = make_inputs(32, 480, 640, seed=317)
+    out, dets = BatchedDetector(m).process_device(*[inp[k].to(DEV) for k in ARGS], static=True)
+    sd = golden_state_dict(0)
+    for i in (0, 15, 31):
+        ref = oracle.plan_a_window_forward(sd, *[inp[k][i:i + 1] for k in ARGS])
+        d = (torch.logit(out["hm"][i:i + 1].cpu().clamp(1e-7, 1 - 1e-7)) - ref["hm"]).abs()
+        assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (i, float(d.max()), float(d.mean()))
+        for k in ("reg", "tracking"):
+            d = (out[k][i:i + 1].cpu() - ref[k]).abs()
+            assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (i, k, float(d.max()))
+    assert dets["kp"].shape == (32, 7, 3)
+    m.engine().bufs.clear()
+    torch.cuda.empty_cache()
+
+
+def test_bench_cli_bf16_and_temporal_window_lines():
+    """bench.py --dtype bf16 and --arch dlapawdT_34 --frames 4 (BASELINE configs[2] / configs[4] shapes, small): one JSON
+    line each, dtype / unit / roofline fields as the contract asks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
+            "--height", "128", "--width", "160", "--no-cpu-baseline"]
+    for extra, dtype, unit in ((["--dtype", "bf16"], "bf16", "frame-pairs/s"),
+                               (["--arch", "dlapawdT_34", "--frames", "4"], "f32", "frame-windows/s")):
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        r = json.loads(lines[0])
+        assert r["dtype"] == dtype and r["unit"] == unit and r["value"] > 0
+        assert 0 < r["roofline"]["frac"] <= 1.0
