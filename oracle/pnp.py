@@ -270,7 +270,7 @@ def gn_fun(value, x2d, x3d, weights, camera):
 
 def gn_dfun(value, x2d, x3d, weights, camera):
     """LM.py:163-221: the Jacobian of ``gn_fun`` (closed form of the reference's sympy expressions), INCLUDING the
-    reference's slip: in every y row the d/dqz entry is a copy of the d/dqy entry (LM.py:207-208 are the same expression;
+    reference's slip: in every y row the d/dqz entry is a copy of the d/dqy entry (LM.py:196-197 are the same expression;
     the fixture generated from the reference's own ``dfun`` pins it)."""
     fx, cx, fy, cy = camera[0][0], camera[0][2], camera[1][1], camera[1][2]
     q, t = np.asarray(value[:4], np.float64), np.asarray(value[4:], np.float64)
@@ -295,7 +295,7 @@ def gn_dfun(value, x2d, x3d, weights, camera):
             g = w_ ** 2 * (m - pr)
             row = list(g * (-2 * dpr_q))
             if k == 1:
-                row[3] = row[2]            # the reference's y rows repeat the d/dqy entry in the d/dqz slot (LM.py:207-208): kept
+                row[3] = row[2]            # the reference's y rows repeat the d/dqy entry in the d/dqz slot (LM.py:196-197): kept
             dt = [0.0, 0.0, 0.0]
             dt[k] = -2 * f_ * g / X[2]
             dt[2] = g * (-2 * c_ / X[2] + 2 * num / X[2] ** 2)
