@@ -1088,7 +1088,8 @@ def test_batched_pnp_and_gauss_newton_match_oracle(ops, model):
     for b, p in enumerate(probs):
         if _gn_converged(op, K, x3d, p):
             n_conv += 1
-            assert np.abs(got[b] - p["gn"]).max() < 1e-5, b
+            # the loop stops when sum|delta| <= 1e-4: end values agree to that order, not to rounding
+            assert np.abs(got[b] - p["gn"]).max() < 5e-4, b
     assert n_conv >= 3
     q1, T1, it1 = pnp.register_GN_C(np.stack([p["x2d"] for p in probs]), X, v0[:, :4], v0[:, 4:], None, K, valid=valid, max_iter=1)
     for b, p in enumerate(probs):
