@@ -314,24 +314,26 @@ int sgta_gn_refine(const double* value0, const double* x2d, const double* x3d, c
                    sgta_stream_t stream);
 
 /* ---- bf16 data path (BASELINE configs[2]: bf16 feature maps / weights, fp32 accumulate / softmax / LayerNorm / decode) ----
- * Feature maps are bf16 CHANNELS-LAST [N,H,W,ld] (``ld`` = channels of the underlying buffer, so a tensor may be a
- * channel slice of a concatenation buffer); weights are bf16 in the packed LDS-image layouts produced by
+ * Feature maps are bf16 BLOCKED channels-last [N][C/16][H][W][16]: a tensor may be a range of 16-channel blocks of a larger
+ * (concatenation) buffer -- every entry point takes the pointer at the view's first block and ``*_bs`` = elements per
+ * image of the underlying buffer; weights are bf16 in the packed LDS-image layouts produced by
  * sgtapose_amd/ops_bf16.py; all matrix products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  What leaves
  * the bf16 domain is fp32: DCN offsets / mask logits, head outputs, attention tokens, decode. */
 
 /* conv (3x3 stride 1 / 2, pad 1; 1x1) + folded BN bias (+ residual before the activation) (+ ReLU): the bf16 twin of
  * sgta_conv2d_f32 (dla.py:41-69, :157-231, :302-312; DCN offset conv; heads base_model.py:121-135).
  * x_bytes / wt_bytes: bytes addressable from x / wt (< 2^31).  wt: [Cout tile][Cin/kc][tap][32*na][kc] bf16, rows
- * XOR-swizzled in 16-byte pieces.  out_mode 0: y bf16 NHWC [N,Ho,Wo,ldy]; 2: y f32 NHWC; 1: y f32 NCHW [N,Cout,Ho,Wo]
+ * XOR-swizzled in 16-byte pieces.  res: bf16 blocked at the output resolution or NULL.  out_mode 0: y bf16 blocked (y_bs
+ * elements per image); 2: y f32 NHWC [N,Ho,Wo,y_bs]; 1: y f32 NCHW [N,Cout,Ho,Wo]
  * with sigmoid on channels < nsig (SGTADetector._sigmoid_output, sgta_detector.py:854-862).  kc = 16 (3x3) / 32 (1x1),
  * Cin % kc == 0; na in {1,2,4} (2 max for stride 2); npf = 32-position fragments per wave (2: 512-position tiles, 1: 256;
  * stride 2 needs 1); log_tw = log2 of the tile width (3..6). */
-int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt_bytes, const float* bias,
-                   const void* res, int ldr, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
+int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
+                   const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
                    int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
                    sgta_stream_t stream);
 
-/* DeformConv (dla.py:538-550) = lbin/DCNv2 modulated deformable 3x3 conv + folded BN + ReLU on bf16 NHWC maps -- the
+/* DeformConv (dla.py:538-550) = lbin/DCNv2 modulated deformable 3x3 conv + folded BN + ReLU on bf16 blocked maps -- the
  * ``sgta_dcnv2_fwd_bf16`` of SURVEY.md section 8b.  om: f32 NHWC [N,H,W,ldo], channels 0..17 = (dy, dx) per tap,
  * 18..26 = mask logits (raw conv_offset_mask output, sigmoid applied here); sampling coordinates and bilinear /
  * mask weights in fp32, the gathered corners are bf16 (16-byte channel runs), blend in fp32, product on bf16 MFMA.
@@ -339,30 +341,30 @@ int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt
  * staged in LDS (offsets up to +-6 pixels; beyond that a wave falls back to gathers from global memory, same arithmetic),
  * converted once per 16-channel chunk to fp16 and blended by v_fma_mix_f32.
  * wt: [Cout tile][Cin/16][9][32*na][16] bf16 swizzled (the 3x3 layout of sgta_conv_bf16); Cin % 16 == 0; na in {2,4}; log_tw 3..5. */
-int sgta_dcnv2_fwd_bf16(const void* x, int ldx, const float* om, int ldo, const void* wt, long wt_bytes,
-                        const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
+int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
+                        const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
                         int na, int log_tw, int act, sgta_stream_t stream);
 
-/* fused 7x7 stems (dla.py:259-270, :324-328): fp32 NCHW image [B,3,H,W] + prior map [B,1,H,W] in, bf16 NHWC
- * [B,H,W,ldy] (16 channels) out; weights / bias as sgta_conv_c16_f32 mode 1. */
+/* fused 7x7 stems (dla.py:259-270, :324-328): fp32 NCHW image [B,3,H,W] + prior map [B,1,H,W] in, bf16 [B,H,W,ldy]
+ * (16 channels; ldy = 16 is the one-block blocked layout [B][1][H][W][16]) out; weights / bias as sgta_conv_c16_f32 mode 1. */
 int sgta_stem_bf16(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt, const float* bias,
                    void* y, int ldy, int B, int H, int W, sgta_stream_t stream);
 
-/* MaxPool2d(2,2) (dla.py:218-220) on bf16 NHWC. */
-int sgta_maxpool2_bf16(const void* x, int ldx, void* y, int ldy, int N, int C, int H, int W, sgta_stream_t stream);
+/* MaxPool2d(2,2) (dla.py:218-220) on bf16 blocked maps. */
+int sgta_maxpool2_bf16(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, sgta_stream_t stream);
 
-/* IDAUp's depthwise ConvTranspose2d(C,C,2f,stride f,pad f/2,groups C) + skip add (dla.py:571-577) on bf16 NHWC;
- * w f32 [2f][2f][C]; skip (bf16 NHWC at the output resolution) may be NULL. */
-int sgta_upsample_add_bf16(const void* x, int ldx, const float* w, const void* skip, int ld_skip, void* y, int ldy,
+/* IDAUp's depthwise ConvTranspose2d(C,C,2f,stride f,pad f/2,groups C) + skip add (dla.py:571-577) on bf16 blocked maps;
+ * w f32 [2f][2f][C]; skip (bf16 blocked at the output resolution) may be NULL. */
+int sgta_upsample_add_bf16(const void* x, long x_bs, const float* w, const void* skip, long skip_bs, void* y, long y_bs,
                            int N, int C, int H, int W, int f, sgta_stream_t stream);
 
-/* get_topk_features_scale's gather (dla.py:961-968) from a bf16 NHWC map into fp32 token rows
+/* get_topk_features_scale's gather (dla.py:961-968) from a bf16 blocked map into fp32 token rows
  * tok[b*n + t][col0 + c], and substitute_topk_features_scale's ordered write-back (dla.py:1012-1014, winners of
- * sgta_window_index only) of fp32 token rows into the bf16 NHWC map. */
-int sgta_window_gather_bf16(const void* feats, int ldf, const long long* fid, float* tok, int B, int C, int H,
+ * sgta_window_index only) of fp32 token rows into the bf16 blocked map. */
+int sgta_window_gather_bf16(const void* feats, long feats_bs, const long long* fid, float* tok, int B, int C, int H,
                             int W, int n, int ld, int col0, sgta_stream_t stream);
 int sgta_window_scatter_bf16(const float* tok, int ldt, const long long* fid, const unsigned char* win,
-                             void* feats, int ldf, int B, int C, int H, int W, int n, sgta_stream_t stream);
+                             void* feats, long feats_bs, int B, int C, int H, int W, int n, sgta_stream_t stream);
 
 #ifdef __cplusplus
 }

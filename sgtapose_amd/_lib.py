@@ -45,13 +45,13 @@ SIGNATURES = {
     "sgta_peaks_decode_kp": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_render_priors": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_post_process": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p],
-    "sgta_conv_bf16": [_p, _l, _i, _p, _l, _p, _p, _i, _p, _i] + [_i] * 14 + [_p],
-    "sgta_dcnv2_fwd_bf16": [_p, _i, _p, _i, _p, _l, _p, _p, _i] + [_i] * 8 + [_p],
+    "sgta_conv_bf16": [_p, _l, _l, _p, _l, _p, _p, _l, _p, _l] + [_i] * 14 + [_p],
+    "sgta_dcnv2_fwd_bf16": [_p, _l, _p, _i, _p, _l, _p, _p, _l] + [_i] * 8 + [_p],
     "sgta_stem_bf16": [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _p],
-    "sgta_maxpool2_bf16": [_p, _i, _p, _i, _i, _i, _i, _i, _p],
-    "sgta_upsample_add_bf16": [_p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
-    "sgta_window_gather_bf16": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
-    "sgta_window_scatter_bf16": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_maxpool2_bf16": [_p, _l, _p, _l, _i, _i, _i, _i, _p],
+    "sgta_upsample_add_bf16": [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "sgta_window_gather_bf16": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_window_scatter_bf16": [_p, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
     "sgta_pre_process": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_pnp_batched": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "sgta_gn_refine": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

@@ -2,10 +2,13 @@
 // maps with bf16 weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Replaces the same reference code as
 // sgta_conv2d_f32 (dla.py:41-69, :157-231, :302-312; DCN offset/mask conv; heads base_model.py:121-135).
 //
-// Layout: channels-last, so the MFMA B operand of a pixel (8 consecutive k = 8 consecutive input channels of one tap)
-// is ONE 16-byte read, and the A operand (8 consecutive k of one output channel) is one 16-byte read of the packed
-// weights.  D[cout, pixel]: the pixel sits on the lane, 4 consecutive output channels in 4 accumulator registers ->
-// 8-byte bf16 NHWC stores (or fp32 NHWC / fp32 NCHW for the tensors that leave the bf16 domain).
+// Layout: BLOCKED channels-last [N][C/16][H][W][16] (bf16): the MFMA B operand of a pixel (8 consecutive k = 8 consecutive
+// input channels of one tap) is ONE 16-byte read, the 16-channel chunk of a window row is ONE contiguous run of global
+// memory (the LDS-DMA moves whole cache lines: with plain NHWC a 16-channel chunk was 32 bytes out of every pixel's
+// C*2-byte row, a quarter of each line at C = 64, and the window fetch cost 20-60 % of the conv kernels), and a wave's
+// output store (32 pixels x 16 channels) is 1 KB contiguous.  The A operand (8 consecutive k of one output channel) is
+// one 16-byte read of the packed weights.  D[cout, pixel]: the pixel sits on the lane, 4 consecutive output channels in
+// 4 accumulator registers (fp32 NHWC / fp32 NCHW stores for the tensors that leave the bf16 domain).
 //
 // Tiling: the batch is ONE tall image of N*(H+1) rows (one zero row under every image, so a tile may span images and
 // every tap is a constant LDS offset); a 512-thread work-group owns TR x TW = 256 / 512 output positions x TC = 32 / 64 /
@@ -20,11 +23,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct CbArgs {
-  const void* x;    long x_bytes;  int ldx;      // bf16 NHWC input (pointer at the view's first channel), bytes reachable
+  const void* x;    long x_bytes;  long x_bs;    // bf16 blocked input (pointer at the view's first 16-channel block), bytes reachable, elements per image
   const void* wt;   long wt_bytes;               // packed [n_ct][nchunks][taps][TC][KC] bf16, swizzled
   const float* bias;                             // [n_ct * TC]
-  const __bf16* res; int ldr;                    // residual, bf16 NHWC at the output resolution (or null)
-  void* y;          int ldy;                     // bf16 NHWC / fp32 NHWC (ldy = channels per pixel) or fp32 NCHW
+  const __bf16* res; long res_bs;                // residual, bf16 blocked at the output resolution (or null)
+  void* y;          long y_bs;                   // bf16 blocked (elements per image) / fp32 NHWC (channels per pixel) / fp32 NCHW (unused)
   int N, H, W, Ho, Wo, Cout, nchunks, n_ct, n_rt, n_xt, log_tw, act, out_mode, nsig;
 };
 
@@ -81,11 +84,15 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       if (Rin >= 0 && (unsigned)x < (unsigned)a.W) {
         const int n = Rin / Hp, y = Rin - n * Hp;
         if (n < a.N && y < a.H) {
-          const int piece = pp ^ ((slot >> LOG_R) & (P - 1));
-          off = (unsigned)(((((long)n * a.H + y) * a.W + x) * a.ldx + piece * 8) * 2);
+          const int piece = pp ^ ((slot >> LOG_R) & (P - 1));        // logical 8-channel piece of the chunk
+          // block (piece >> 1) of the chunk, half (piece & 1) of the pixel's 16-channel run
+          off = (unsigned)(((long)n * a.x_bs + (long)(piece >> 1) * a.H * a.W * 16 + ((long)y * a.W + x) * 16 + (piece & 1) * 8) * 2);
         }
       }
     }
+#if defined(CB_ABLATE) && (CB_ABLATE & 1)
+    off = 0x80000000u;                             // tools only: no window fetch (the DMA still writes zeros)
+#endif
     woff[t] = off;
   }
   unsigned aoffw[AROUNDS];
@@ -93,24 +100,31 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   for (int t = 0; t < AROUNDS; ++t) {
     const int e = (t * 512 + tid) * 16;
     aoffw[t] = e < WIMG ? (unsigned)e : 0x80000000u;
+#if defined(CB_ABLATE) && (CB_ABLATE & 2)
+    aoffw[t] = 0x80000000u;                        // tools only: no weight fetch
+#endif
   }
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
   __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), (short)0, (int)a.wt_bytes, 0x00020000);
 #endif
-  auto stage = [&](int kc, int st) {
+  // DMA instruction j (0 .. NDMA-1) of chunk kc into stage st: window rounds first, then the weight image
+  constexpr int NDMA = G::WROUNDS + AROUNDS;
+  auto dma_one = [&](int j, int kc, int st) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned char* wdst = smem + st * STAGE + wave * 1024;
-    unsigned char* adst = wdst + G::WIN_BYTES;
-#pragma unroll
-    for (int t = 0; t < G::WROUNDS; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * 8192), 16, woff[t], kc * ROWB, 0, 0);
-#pragma unroll
-    for (int t = 0; t < AROUNDS; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * 8192), 16, aoffw[t],
-                                               (ct * a.nchunks + kc) * WIMG, 0, 0);
+    if (j < G::WROUNDS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + j * 8192), 16, woff[j < G::WROUNDS ? j : 0],
+                                               kc * (KC / 16) * a.H * a.W * 32, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wdst + G::WIN_BYTES + (j - G::WROUNDS) * 8192), 16,
+                                               aoffw[j >= G::WROUNDS ? j - G::WROUNDS : 0], (ct * a.nchunks + kc) * WIMG, 0, 0);
 #endif
+  };
+  auto stage = [&](int kc, int st) {
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) dma_one(j, kc, st);
   };
 
   // ---- per-lane output positions and LDS fragment addresses -----------------------------------------------------
@@ -150,30 +164,44 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
     const int st = kc & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kc + 1 < a.nchunks) stage(kc + 1, st ^ 1);
+    const bool more = kc + 1 < a.nchunks;          // the next chunk's DMA is issued piece by piece between the MFMA groups below
     const unsigned char* Ws = smem + st * STAGE;
     const unsigned char* As = Ws + G::WIN_BYTES;
+    // software pipeline over the k-steps of the chunk: the fragments of step k + 1 are requested before the MFMAs of step
+    // k issue, so the LDS latency sits under matrix work of the SAME wave (the two waves of a SIMD run this loop in
+    // lock-step after the barrier and would otherwise wait on LDS together, then contend for the matrix pipe together)
+    constexpr int NK = TAPS * KSTEPS;
+    bf16x8 afr[2][NA], bfr[2][NPF];
+    auto frags = [&](int k, bf16x8 (&af)[NA], bf16x8 (&bf)[NPF]) {
+      const int t = k / KSTEPS, s_ = k % KSTEPS;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+      for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr[s_]);
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        bf16x8 af[NA], bfr[NPF];
+      for (int f = 0; f < NPF; ++f) bf[f] = *reinterpret_cast<const bf16x8*>(Ws + baddr[k][f]);
+    };
+    // (a burst of NDMA LDS-DMA instructions right behind the barrier stalls the CU's single texture-address path while the
+    // matrix pipes idle: one or two per k-step instead)
+    constexpr int DPK = (NDMA + NK - 1) / NK;
+    frags(0, afr[0], bfr[0]);
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-          af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr[s]);
+    for (int k = 0; k < NK; ++k) {
+      if (k + 1 < NK) frags(k + 1, afr[(k + 1) & 1], bfr[(k + 1) & 1]);
 #pragma unroll
-        for (int f = 0; f < NPF; ++f) bfr[f] = *reinterpret_cast<const bf16x8*>(Ws + baddr[t * KSTEPS + s][f]);
+      for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
+        for (int f = 0; f < NPF; ++f)
+          acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[k & 1][i], bfr[k & 1][f], acc[i][f], 0, 0, 0);
+      if (more) {
 #pragma unroll
-          for (int f = 0; f < NPF; ++f)
-            acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[f], acc[i][f], 0, 0, 0);
+        for (int d = 0; d < DPK; ++d)
+          if (k * DPK + d < NDMA) dma_one(k * DPK + d, kc + 1, st ^ 1);
       }
+    }
   }
 
   // ---- epilogue: C/D layout col = lane & 31 (position), row = (q & 3) + 8 (q >> 2) + 4 h (output channel) ----------
   const long HWo = (long)a.Ho * a.Wo;
-  auto value4 = [&](int i, int f, int g4, long pix) {          // bias + residual + activation of 4 consecutive channels
+  auto value4 = [&](int i, int f, int g4) {                    // bias + residual + activation of 4 consecutive channels
     const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (co0 < a.Cout) {
@@ -181,7 +209,8 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[i][f][4 * g4 + j] + bv[j];
       if (a.res) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + pix * a.ldr + co0);
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + (long)pn[f] * a.res_bs + (long)(co0 >> 4) * HWo * 16 +
+                                                           (long)prem[f] * 16 + (co0 & 15));
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
       }
@@ -197,7 +226,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
     if (prem[f] < 0) continue;                                 // both lane halves of a position agree (same r)
     const long pix = (long)pn[f] * HWo + prem[f];
     if (a.out_mode == 0 && (a.Cout & 7) == 0) {
-      // bf16 NHWC: a lane holds channels {8 g4 + 4 h ..+3}; exchanging the odd group of the lower lane half with the even
+      // bf16 blocked: a lane holds channels {8 g4 + 4 h ..+3}; exchanging the odd group of the lower lane half with the even
       // group of the upper half (v_permlane32_swap) gives every lane 8 consecutive channels = one 16-byte store, and the
       // two halves of a position 32 contiguous bytes (8-byte stores were written back sector by sector: 2.5x the bytes)
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -206,14 +235,15 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const bf16x4 pb = __builtin_convertvector(value4(i, f, 2 * m, pix), bf16x4);
-          const bf16x4 qb = __builtin_convertvector(value4(i, f, 2 * m + 1, pix), bf16x4);
+          const bf16x4 pb = __builtin_convertvector(value4(i, f, 2 * m), bf16x4);
+          const bf16x4 qb = __builtin_convertvector(value4(i, f, 2 * m + 1), bf16x4);
           const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
           const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
           const int co = ct * TC + i * 32 + 16 * m + 8 * h;
-          if (co < a.Cout)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.y) + pix * a.ldy + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          if (co < a.Cout)                       // blocked: block co >> 4, the lane's half (8 h) of the pixel's 16-channel run
+            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.y) + (long)pn[f] * a.y_bs + (long)(co >> 4) * HWo * 16 +
+                                      (long)prem[f] * 16 + (co & 15)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
       continue;
     }
@@ -223,11 +253,12 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       for (int g4 = 0; g4 < 4; ++g4) {
         const int co0 = ct * TC + i * 32 + 8 * g4 + 4 * h;
         if (co0 >= a.Cout) continue;
-        const f32x4 v = value4(i, f, g4, pix);
+        const f32x4 v = value4(i, f, g4);
         if (a.out_mode == 0) {
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + pix * a.ldy + co0) = __builtin_convertvector(v, bf16x4);
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + (long)pn[f] * a.y_bs + (long)(co0 >> 4) * HWo * 16 +
+                                     (long)prem[f] * 16 + (co0 & 15)) = __builtin_convertvector(v, bf16x4);
         } else if (a.out_mode == 2) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pix * a.ldy + co0) = v;
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pix * a.y_bs + co0) = v;
         } else {
           float* yb = reinterpret_cast<float*>(a.y) + ((long)pn[f] * a.Cout + co0) * HWo + prem[f];
 #pragma unroll
@@ -259,25 +290,28 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
   return SGTA_OK;
 }
 
-// x: bf16 NHWC [N,H,W,ldx] (pointer at the first input channel of the view; x_bytes = bytes from x to the end of the
-// allocation that may be addressed, < 2^31); wt: sgta_conv_bf16_pack layout for (ks, stride, kc, na); bias f32
-// [n_ct*32*na]; res: bf16 NHWC [N,Ho,Wo,ldr] or NULL (added before the activation); out_mode 0: y bf16 NHWC [..,ldy],
-// 2: y f32 NHWC [..,ldy], 1: y f32 NCHW [N,Cout,Ho,Wo] with sigmoid on channels < nsig.  act: 0 none, 1 ReLU.
+// x: bf16 blocked [N][Cb][H][W][16] (pointer at the first 16-channel block of the view; x_bs = elements per image of the
+// underlying buffer; x_bytes = bytes from x to the end of the allocation that may be addressed, < 2^31); wt: ops_bf16.py
+// layout for (ks, stride, kc, na); bias f32 [n_ct*32*na]; res: bf16 blocked at the output resolution (res_bs elements
+// per image) or NULL (added before the activation); out_mode 0: y bf16 blocked (y_bs elements per image), 2: y f32 NHWC
+// [N,Ho,Wo,y_bs], 1: y f32 NCHW [N,Cout,Ho,Wo] with sigmoid on channels < nsig.  act: 0 none, 1 ReLU.
 // npf: 32-position fragments per wave (2: 512-position tiles; 1: 256; stride 2 needs 1); log_tw: log2 of the tile width
 // (3..6).  Cin % kc == 0, kc in {16 (3x3), 32 (1x1)}.
-extern "C" int sgta_conv_bf16(const void* x, long x_bytes, int ldx, const void* wt, long wt_bytes, const float* bias,
-                              const void* res, int ldr, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
+extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
+                              const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
                               int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
                               hipStream_t st) {
   if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SGTA_EBADARG;
   if (x_bytes <= 0 || x_bytes > 0x7fffffffL || wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
-  if (Cin % kc || (ldx % 8) || log_tw < 3 || log_tw > 6 || act < 0 || act > 1 || out_mode < 0 || out_mode > 2) return SGTA_EBADARG;
-  if (out_mode != 1 && (ldy % 4 || Cout % 4)) return SGTA_EBADARG;
-  if (out_mode == 0 && Cout % 8 == 0 && (ldy % 8 || ((uintptr_t)y & 15))) return SGTA_EBADARG;     // 16-byte stores
-  if (res && ldr % 4) return SGTA_EBADARG;
+  if (Cin % kc || (x_bs % 16) || ((uintptr_t)x & 15) || log_tw < 3 || log_tw > 6 || act < 0 || act > 1 || out_mode < 0 ||
+      out_mode > 2)
+    return SGTA_EBADARG;
+  if (out_mode == 2 && (y_bs % 4 || Cout % 4)) return SGTA_EBADARG;
+  if (out_mode == 0 && (Cout % 4 || y_bs % 16 || ((uintptr_t)y & 15))) return SGTA_EBADARG;        // 16-byte stores
+  if (res && (res_bs % 16 || ((uintptr_t)res & 7))) return SGTA_EBADARG;
   CbArgs a;
-  a.x = x; a.x_bytes = x_bytes; a.ldx = ldx; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
-  a.res = reinterpret_cast<const __bf16*>(res); a.ldr = ldr; a.y = y; a.ldy = ldy;
+  a.x = x; a.x_bytes = x_bytes; a.x_bs = x_bs; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
+  a.res = reinterpret_cast<const __bf16*>(res); a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cout = Cout;
   a.nchunks = Cin / kc; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act; a.out_mode = out_mode; a.nsig = nsig;
   if (npf != 1 && npf != 2) return SGTA_EBADARG;

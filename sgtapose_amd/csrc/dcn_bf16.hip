@@ -1,5 +1,5 @@
 // bf16 data path: modulated deformable 3x3 convolution (lbin/DCNv2 semantics) + folded BN +
-// ReLU on bf16 NHWC feature maps; replaces DeformConv (dla.py:538-550) like sgta_dcnv2_lds_f32 does in fp32.
+// ReLU on bf16 blocked channels-last feature maps ([N][C/16][H][W][16]); replaces DeformConv (dla.py:538-550) like sgta_dcnv2_lds_f32 does in fp32.
 //
 // Channels-last makes the deformable gather coalesced: one sampling corner of one pixel is a run of consecutive
 // channels, so a lane fetches 8 channels (16 bytes) per corner, blends the four corners in fp32 with its per-(pixel, tap)
@@ -15,11 +15,11 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct DbArgs {
-  const __bf16* x;  int ldx;  long x_bytes;      // bf16 NHWC input [N,H,W,ldx] (pointer at the view's first channel), its extent
+  const __bf16* x;  long x_bs;  long x_bytes;    // bf16 blocked input [N][Cb][H][W][16] (pointer at the view's first block), elements per image, extent
   const float* om;  int ldo;                     // f32 NHWC offsets / mask logits [N,H,W,ldo]: ldo >= 28, ldo % 4 == 0 (read as 7 x 16 bytes)
   const void* wt;   long wt_bytes;               // packed [n_ct][Cin/16][9][TC][16] bf16, swizzled
   const float* bias;                             // [n_ct * TC]
-  __bf16* y;        int ldy;                     // bf16 NHWC output
+  __bf16* y;        long y_bs;                   // bf16 blocked output, elements per image
   int N, H, W, Cin, Cout, ngroups, n_ct, n_rt, n_xt, log_tw, act;
   unsigned mH, mWC[3];                           // ceil(2^32 / H), ceil(2^32 / window columns) for log_tw 3..5 (umulhi division)
 };
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
       const int Rs = R0 + wr, x = X0 + wc;
       if (Rs >= 0 && Rs < a.N * H && (unsigned)x < (unsigned)W) {
         const int piece = pp ^ ((slot >> 3) & 1);
-        off = (unsigned)((((long)Rs * W + x) * a.ldx + piece * 8) * 2);
+        const int ni = db_div(Rs, a.mH), yi = Rs - ni * H;
+        off = (unsigned)(((long)ni * a.x_bs + ((long)yi * W + x) * 16 + piece * 8) * 2);
       }
     }
     woff[t] = off;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
     unsigned char* adst = wdst + WIN_BYTES;
 #pragma unroll
     for (int t = 0; t < WROUNDS; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * NT * 16), 16, woff[t], kc * ROWB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + t * NT * 16), 16, woff[t], kc * H * W * 32, 0, 0);
 #pragma unroll
     for (int t = 0; t < AROUNDS; ++t)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(adst + t * NT * 16), 16, aoffw[t],
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
     }
   } else {
     const float* o = a.om + (pix >= 0 ? pix : 0) * a.ldo;
-    const int nb = (okp ? n : 0) * H;
+    const int nb = okp ? n : 0;
     for (int kc = 0; kc < nchunks; ++kc) {
       if (kc) {
         __builtin_amdgcn_s_barrier();
@@ -294,9 +295,9 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int yy = (k >> 1) ? cy1 : cy0, xx = (k & 1) ? cx1 : cx0;
-          const unsigned off = (unsigned)((((long)(nb + yy) * W + xx) * a.ldx + h * 8) * 2);
+          const unsigned off = (unsigned)(((long)nb * a.x_bs + ((long)yy * W + xx) * 16 + h * 8) * 2);
 #if defined(__HIP_DEVICE_COMPILE__)
-          cv[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, kc * ROWB, 0));
+          cv[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, kc * H * W * 32, 0));
 #endif
         }
         blend_mma(cv, w4, As, t);
@@ -331,7 +332,9 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
         const int co = ct * TC + i * 32 + 16 * m + 8 * h;
-        if (co < a.Cout) *reinterpret_cast<u32x4*>(a.y + pix * a.ldy + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        if (co < a.Cout)
+          *reinterpret_cast<u32x4*>(a.y + (long)n * a.y_bs + (long)(co >> 4) * H * W * 16 + ((long)yp * W + xp) * 16 + (co & 15)) =
+              u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
   }
 }
@@ -353,22 +356,23 @@ static int db_launch(DbArgs& a, hipStream_t st) {
   return SGTA_OK;
 }
 
-// x bf16 NHWC [N,H,W,ldx]; om f32 NHWC [N,H,W,ldo]: channels 0..17 = (dy, dx) per tap, 18..26 = mask logits (the raw
+// x bf16 blocked [N][Cb][H][W][16] (x_bs elements per image); om f32 NHWC [N,H,W,ldo]: channels 0..17 = (dy, dx) per tap, 18..26 = mask logits (the raw
 // conv_offset_mask output); wt: [n_ct][Cin/16][9][32*na][16] bf16 rows XOR-swizzled in 16-byte pieces (the 3x3 layout of
-// sgta_conv_bf16, ops_bf16.py); bias f32 [n_ct*32*na] (BN folded); y bf16 NHWC [N,H,W,ldy]; act 1 = ReLU.
+// sgta_conv_bf16, ops_bf16.py); bias f32 [n_ct*32*na] (BN folded); y bf16 blocked (y_bs elements per image); act 1 = ReLU.
 // Cin % 16 == 0, Cout % 8 == 0, log_tw in 3..5.
-extern "C" int sgta_dcnv2_fwd_bf16(const void* x, int ldx, const float* om, int ldo, const void* wt, long wt_bytes,
-                                   const float* bias, void* y, int ldy, int N, int H, int W, int Cin, int Cout,
+extern "C" int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
+                                   const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
                                    int na, int log_tw, int act, hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
-  if (Cin % 16 || Cout % 8 || ldx % 8 || ldy % 8 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 28 || ldo % 4 || ((uintptr_t)om & 15) || log_tw < 3 ||
+  if (Cin % 16 || Cout % 8 || x_bs % 16 || y_bs % 16 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 28 || ldo % 4 || ((uintptr_t)om & 15) || log_tw < 3 ||
       log_tw > 5)
     return SGTA_EBADARG;
   if (wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
-  if ((long)N * H * W * ldx * 2 > 0x7fffffffL) return SGTA_EBADARG;      // 31-bit byte offsets in the gather
+  if ((long)N * x_bs * 2 > 0x7fffffffL) return SGTA_EBADARG;             // 31-bit byte offsets in the gather
   DbArgs a;
-  a.x = reinterpret_cast<const __bf16*>(x); a.ldx = ldx; a.x_bytes = ((long)N * H * W - 1) * ldx * 2 + (long)Cin * 2; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
-  a.bias = bias; a.y = reinterpret_cast<__bf16*>(y); a.ldy = ldy; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.x = reinterpret_cast<const __bf16*>(x); a.x_bs = x_bs;
+  a.x_bytes = ((long)(N - 1) * x_bs + (long)(Cin / 16) * H * W * 16) * 2; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
+  a.bias = bias; a.y = reinterpret_cast<__bf16*>(y); a.y_bs = y_bs; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.ngroups = Cin / 16; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act;
   if (na == 2) return db_launch<2>(a, st);
   if (na == 4) return db_launch<4>(a, st);

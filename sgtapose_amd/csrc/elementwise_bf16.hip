@@ -1,4 +1,5 @@
-// bf16 data path: the memory-bound glue of the channels-last engine (one thread = 8 channels = one 16-byte access):
+// bf16 data path: the memory-bound glue of the blocked channels-last engine ([N][C/16][H][W][16]; one thread = 8 channels of
+// one pixel = one 16-byte access; ``bs`` = elements per image of the underlying buffer, pointers at the view's first block):
 // MaxPool2d(2,2) (dla.py:218-220), depthwise ConvTranspose2d up-sampling + skip add (IDAUp, dla.py:571-577),
 // window token gather / ordered scatter between bf16 NHWC maps and the fp32 token matrices of the attention stage
 // (get_topk_features_scale / substitute_topk_features_scale, dla.py:915-968, :1006-1018).
@@ -12,31 +13,34 @@ __device__ __forceinline__ f32x8 ld8(const __bf16* p) {
   return __builtin_convertvector(v, f32x8);
 }
 
-__global__ __launch_bounds__(256) void maxpool2_bf16_kernel(const __bf16* __restrict__ x, int ldx, __bf16* __restrict__ y,
-                                                            int ldy, int C8, int H, int W, long total) {
+__global__ __launch_bounds__(256) void maxpool2_bf16_kernel(const __bf16* __restrict__ x, long x_bs, __bf16* __restrict__ y,
+                                                            long y_bs, int C8, int H, int W, long total) {
   const int Ho = H / 2, Wo = W / 2;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C8) * 8;
-    long p = i / C8;
+    const int half = (int)(i & 1);                 // which 8 of the pixel's 16-channel run: adjacent threads -> adjacent 16 bytes
+    long p = i >> 1;
     const int xo = (int)(p % Wo);
     p /= Wo;
     const int yo = (int)(p % Ho);
-    const long n = p / Ho;
-    const __bf16* s = x + ((n * H + 2 * yo) * W + 2 * xo) * ldx + c;
-    const f32x8 a = ld8(s), b = ld8(s + ldx), d = ld8(s + (long)W * ldx), e = ld8(s + (long)(W + 1) * ldx);
+    p /= Ho;
+    const int cb = (int)(p % (C8 / 2));
+    const long n = p / (C8 / 2);
+    const __bf16* s = x + n * x_bs + ((long)cb * H * W + (long)(2 * yo) * W + 2 * xo) * 16 + half * 8;
+    const f32x8 a = ld8(s), b = ld8(s + 16), d = ld8(s + (long)W * 16), e = ld8(s + (long)(W + 1) * 16);
     f32x8 m;
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(d[j], e[j]));
-    *reinterpret_cast<bf16x8*>(y + ((n * Ho + yo) * Wo + xo) * ldy + c) = __builtin_convertvector(m, bf16x8);
+    *reinterpret_cast<bf16x8*>(y + n * y_bs + ((long)cb * Ho * Wo + (long)yo * Wo + xo) * 16 + half * 8) =
+        __builtin_convertvector(m, bf16x8);
   }
 }
 
-extern "C" int sgta_maxpool2_bf16(const void* x, int ldx, void* y, int ldy, int N, int C, int H, int W, hipStream_t st) {
-  if (!x || !y || N <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || H < 2 || W < 2) return SGTA_EBADARG;
+extern "C" int sgta_maxpool2_bf16(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, hipStream_t st) {
+  if (!x || !y || N <= 0 || C <= 0 || C % 16 || x_bs % 16 || y_bs % 16 || H < 2 || W < 2) return SGTA_EBADARG;
   const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
   const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL(maxpool2_bf16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16*>(x), ldx,
-                     reinterpret_cast<__bf16*>(y), ldy, C / 8, H, W, total);
+  hipLaunchKernelGGL(maxpool2_bf16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16*>(x), x_bs,
+                     reinterpret_cast<__bf16*>(y), y_bs, C / 8, H, W, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
@@ -44,25 +48,28 @@ extern "C" int sgta_maxpool2_bf16(const void* x, int ldx, void* y, int ldy, int 
 // y[n, oy, ox, c] = skip + sum over the (at most) 2 x 2 input pixels that reach the output pixel of
 // x[n, iy, ix, c] * w[ky][kx][c]   (ConvTranspose2d(C, C, 2F, stride F, padding F/2, groups C, bias False))
 template <int F>
-__global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __restrict__ x, long x_bs,
                                                                 const float* __restrict__ w,      // [2F][2F][C]
-                                                                const __bf16* __restrict__ skip, int lds_,
-                                                                __bf16* __restrict__ y, int ldy, int C, int H, int W,
+                                                                const __bf16* __restrict__ skip, long s_bs,
+                                                                __bf16* __restrict__ y, long y_bs, int C, int H, int W,
                                                                 long total) {
   constexpr int KS = 2 * F, P = F / 2;
-  const int Ho = H * F, Wo = W * F, C8 = C / 8;
+  const int Ho = H * F, Wo = W * F, Cb = C / 16;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C8) * 8;
-    long p = i / C8;
+    const int half = (int)(i & 1);
+    long p = i >> 1;
     const int ox = (int)(p % Wo);
     p /= Wo;
     const int oy = (int)(p % Ho);
-    const long n = p / Ho;
+    p /= Ho;
+    const int cb = (int)(p % Cb);
+    const long n = p / Cb;
+    const int c = cb * 16 + half * 8;
     const int iy1 = (oy + P) / F, ky1 = oy + P - iy1 * F, iy0 = iy1 - 1, ky0 = ky1 + F;
     const int ix1 = (ox + P) / F, kx1 = ox + P - ix1 * F, ix0 = ix1 - 1, kx0 = kx1 + F;
-    const long o = (n * Ho + oy) * Wo + ox;
+    const long o = ((long)cb * Ho * Wo + (long)oy * Wo + ox) * 16 + half * 8;
     f32x8 acc;
-    if (skip) acc = ld8(skip + o * lds_ + c);
+    if (skip) acc = ld8(skip + n * s_bs + o);
     else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         if (iys[a] < 0 || iys[a] >= H || ixs[b] < 0 || ixs[b] >= W) continue;
-        const f32x8 v = ld8(x + ((n * H + iys[a]) * W + ixs[b]) * ldx + c);
+        const f32x8 v = ld8(x + n * x_bs + ((long)cb * H * W + (long)iys[a] * W + ixs[b]) * 16 + half * 8);
         const float* wp = w + (long)(kys[a] * KS + kxs[b]) * C + c;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
@@ -82,58 +89,58 @@ __global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __
           acc[4 + j] = __builtin_fmaf(v[4 + j], w1[j], acc[4 + j]);
         }
       }
-    *reinterpret_cast<bf16x8*>(y + o * ldy + c) = __builtin_convertvector(acc, bf16x8);
+    *reinterpret_cast<bf16x8*>(y + n * y_bs + o) = __builtin_convertvector(acc, bf16x8);
   }
 }
 
 // w: f32 [2f][2f][C] (the module's [C,1,2f,2f] weight permuted); skip may be NULL.
-extern "C" int sgta_upsample_add_bf16(const void* x, int ldx, const float* w, const void* skip, int lds_, void* y, int ldy,
+extern "C" int sgta_upsample_add_bf16(const void* x, long x_bs, const float* w, const void* skip, long s_bs, void* y, long y_bs,
                                       int N, int C, int H, int W, int f, hipStream_t st) {
-  if (!x || !w || !y || N <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || (skip && lds_ % 8)) return SGTA_EBADARG;
+  if (!x || !w || !y || N <= 0 || C <= 0 || C % 16 || x_bs % 16 || y_bs % 16 || (skip && s_bs % 16)) return SGTA_EBADARG;
   if (f != 2 && f != 4) return SGTA_EBADARG;
   const long total = (long)N * H * f * W * f * (C / 8);
   const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
   auto xx = reinterpret_cast<const __bf16*>(x);
   auto ss = reinterpret_cast<const __bf16*>(skip);
   auto yy = reinterpret_cast<__bf16*>(y);
-  if (f == 2) hipLaunchKernelGGL(upsample_add_bf16_kernel<2>, dim3(grid), dim3(256), 0, st, xx, ldx, w, ss, lds_, yy, ldy, C, H, W, total);
-  else hipLaunchKernelGGL(upsample_add_bf16_kernel<4>, dim3(grid), dim3(256), 0, st, xx, ldx, w, ss, lds_, yy, ldy, C, H, W, total);
+  if (f == 2) hipLaunchKernelGGL(upsample_add_bf16_kernel<2>, dim3(grid), dim3(256), 0, st, xx, x_bs, w, ss, s_bs, yy, y_bs, C, H, W, total);
+  else hipLaunchKernelGGL(upsample_add_bf16_kernel<4>, dim3(grid), dim3(256), 0, st, xx, x_bs, w, ss, s_bs, yy, y_bs, C, H, W, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
 
-// tok[b*n + t][col0 + c] = float(feats[b][fid[b][t]][c])      (fid = pixel index y*W + x inside the image)
-__global__ __launch_bounds__(256) void window_gather_bf16_kernel(const __bf16* __restrict__ feats, int ldf, long HW,
+// tok[b*n + t][col0 + c] = float(feats[b][c / 16][fid[b][t]][c % 16])      (fid = pixel index y*W + x inside the image)
+__global__ __launch_bounds__(256) void window_gather_bf16_kernel(const __bf16* __restrict__ feats, long f_bs, long HW,
                                                                  const long long* __restrict__ fid, float* __restrict__ tok,
                                                                  int C8, int n, int ld, int col0, long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C8) * 8;
     const long bt = i / C8;
     const long b = bt / n;
-    const f32x8 v = ld8(feats + (b * HW + fid[bt]) * ldf + c);
+    const f32x8 v = ld8(feats + b * f_bs + ((long)(c >> 4) * HW + fid[bt]) * 16 + (c & 15));
     float* d = tok + bt * ld + col0 + c;
     *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
   }
 }
 
-extern "C" int sgta_window_gather_bf16(const void* feats, int ldf, const long long* fid, float* tok, int B, int C, int H,
+extern "C" int sgta_window_gather_bf16(const void* feats, long f_bs, const long long* fid, float* tok, int B, int C, int H,
                                        int W, int n, int ld, int col0, hipStream_t st) {
-  if (!feats || !fid || !tok || B <= 0 || C <= 0 || C % 8 || ldf % 8 || n <= 0 || ld < col0 + C || ld % 4 || col0 % 4)
+  if (!feats || !fid || !tok || B <= 0 || C <= 0 || C % 16 || f_bs % 16 || n <= 0 || ld < col0 + C || ld % 4 || col0 % 4)
     return SGTA_EBADARG;
   const long total = (long)B * n * (C / 8);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(window_gather_bf16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16*>(feats), ldf,
+  hipLaunchKernelGGL(window_gather_bf16_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16*>(feats), f_bs,
                      (long)H * W, fid, tok, C / 8, n, ld, col0, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
 
-// feats[b][fid[b][t]][c] = bf16(tok[b*n + t][c]) for winner tokens only (deterministic last-wins, as sgta_window_scatter)
+// feats[b][c / 16][fid[b][t]][c % 16] = bf16(tok[b*n + t][c]) for winner tokens only (deterministic last-wins, as sgta_window_scatter)
 __global__ __launch_bounds__(256) void window_scatter_bf16_kernel(const float* __restrict__ tok, int ldt,
                                                                   const long long* __restrict__ fid,
                                                                   const unsigned char* __restrict__ win,
-                                                                  __bf16* __restrict__ feats, int ldf, long HW, int C8, int n,
+                                                                  __bf16* __restrict__ feats, long f_bs, long HW, int C8, int n,
                                                                   long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C8) * 8;
@@ -143,17 +150,17 @@ __global__ __launch_bounds__(256) void window_scatter_bf16_kernel(const float* _
     const float* s = tok + bt * ldt + c;
     const f32x4 a = *reinterpret_cast<const f32x4*>(s), d = *reinterpret_cast<const f32x4*>(s + 4);
     const f32x8 v = {a[0], a[1], a[2], a[3], d[0], d[1], d[2], d[3]};
-    *reinterpret_cast<bf16x8*>(feats + (b * HW + fid[bt]) * ldf + c) = __builtin_convertvector(v, bf16x8);
+    *reinterpret_cast<bf16x8*>(feats + b * f_bs + ((long)(c >> 4) * HW + fid[bt]) * 16 + (c & 15)) = __builtin_convertvector(v, bf16x8);
   }
 }
 
 extern "C" int sgta_window_scatter_bf16(const float* tok, int ldt, const long long* fid, const unsigned char* win,
-                                        void* feats, int ldf, int B, int C, int H, int W, int n, hipStream_t st) {
-  if (!tok || !fid || !win || !feats || B <= 0 || C <= 0 || C % 8 || ldf % 8 || ldt % 4 || n <= 0) return SGTA_EBADARG;
+                                        void* feats, long f_bs, int B, int C, int H, int W, int n, hipStream_t st) {
+  if (!tok || !fid || !win || !feats || B <= 0 || C <= 0 || C % 16 || f_bs % 16 || ldt % 4 || n <= 0) return SGTA_EBADARG;
   const long total = (long)B * n * (C / 8);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(window_scatter_bf16_kernel, dim3(grid), dim3(256), 0, st, tok, ldt, fid, win,
-                     reinterpret_cast<__bf16*>(feats), ldf, (long)H * W, C / 8, n, total);
+                     reinterpret_cast<__bf16*>(feats), f_bs, (long)H * W, C / 8, n, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

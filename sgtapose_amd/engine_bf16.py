@@ -1,7 +1,8 @@
 """bf16 data path of ``DLAPlanAWindowL3New.forward`` (BASELINE configs[2]; same call stack as engine.py).
 
-Feature maps are bf16 CHANNELS-LAST [N,H,W,C] in HBM (half the bytes of the fp32 path, and the layout in which
-both the MFMA operand of a pixel and a deformable-sampling corner are one contiguous 16-byte run); weights are bf16;
+Feature maps are bf16 BLOCKED CHANNELS-LAST [N,C/16,H,W,16] in HBM (half the bytes of the fp32 path; the MFMA operand of a
+pixel and a deformable-sampling corner are contiguous 16-byte runs, and a 16-channel chunk of a window row is one
+contiguous run of memory for the LDS-DMA); weights are bf16;
 every product runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (direct-form convs: at the bf16 matrix rate the
 path is memory-bound, so Winograd is neither needed nor numerically wise).  fp32 stays where the reference's
 numerics are fragile or the data are tiny: the boundary inputs and the two 7x7 stems that read them, the DCN
@@ -72,6 +73,9 @@ class EngineBF16(Engine):
         self.P = P
 
     def hbuf(self, name, n, h, w, c, dtype=BF16):
+        """bf16 maps: blocked [n, c/16, h, w, 16]; fp32 maps (DCN offsets): plain channels-last [n, h, w, c]."""
+        if dtype == BF16:
+            return ViewH(self.buf(name, (n, c // 16, h, w, 16), dtype))
         return ViewH(self.buf(name, (n, h, w, c), dtype))
 
     @staticmethod

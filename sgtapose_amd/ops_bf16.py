@@ -1,4 +1,4 @@
-"""Python faces of the bf16 data path (BASELINE configs[2]): bf16 NHWC feature maps and bf16 weights on
+"""Python faces of the bf16 data path (BASELINE configs[2]): bf16 blocked channels-last feature maps ([N, C/16, H, W, 16]) and bf16 weights on
 v_mfma_f32_32x32x16_bf16, fp32 accumulation; everything that leaves the bf16 domain (DCN offsets / masks, head outputs,
 attention tokens, decode) is fp32.  torch is plumbing only; every function enqueues hand-written HIP kernels.
 """
@@ -15,27 +15,30 @@ BF16 = torch.bfloat16
 
 
 class ViewH:
-    """A [N, H, W, C] bfloat16 (or float32) channels-last activation that may be a channel slice of a wider buffer."""
+    """A bfloat16 activation in the BLOCKED channels-last layout [N, C/16, H, W, 16] that may be a range of 16-channel
+    blocks of a wider (concatenation) buffer; also wraps the fp32 channels-last tensors of the path ([N, H, W, C], e.g.
+    the DCN offset maps), for which only N / H / W / C / ld / ptr are meaningful."""
     __slots__ = ("base", "c0", "C")
 
     def __init__(self, base, c0=0, C=None):
-        if not (base.is_cuda and base.is_contiguous() and base.dim() == 4):
-            raise _lib.SgtaHipError("expected a contiguous [N,H,W,C] tensor on the GPU")
+        if not (base.is_cuda and base.is_contiguous() and base.dim() in (4, 5)):
+            raise _lib.SgtaHipError("expected a contiguous [N,C/16,H,W,16] (or fp32 [N,H,W,C]) tensor on the GPU")
         self.base = base
+        ctot = base.shape[1] * 16 if base.dim() == 5 else base.shape[3]
         self.c0 = c0
-        self.C = base.shape[3] - c0 if C is None else C
-        assert 0 <= c0 and c0 + self.C <= base.shape[3]
+        self.C = ctot - c0 if C is None else C
+        assert 0 <= c0 and c0 + self.C <= ctot
+        if base.dim() == 5:
+            assert base.shape[4] == 16 and c0 % 16 == 0 and self.C % 16 == 0, "views are ranges of 16-channel blocks"
 
+    blocked = property(lambda s: s.base.dim() == 5)
     N = property(lambda s: s.base.shape[0])
-    H = property(lambda s: s.base.shape[1])
-    W = property(lambda s: s.base.shape[2])
-    ld = property(lambda s: s.base.shape[3])
-    esize = property(lambda s: s.base.element_size())
-    ptr = property(lambda s: s.base.data_ptr() + s.c0 * s.base.element_size())
-    nbytes = property(lambda s: (s.base.numel() - s.c0) * s.base.element_size())      # addressable from ptr
-
-    def tensor(self):
-        return self.base[..., self.c0:self.c0 + self.C]
+    H = property(lambda s: s.base.shape[2] if s.base.dim() == 5 else s.base.shape[1])
+    W = property(lambda s: s.base.shape[3] if s.base.dim() == 5 else s.base.shape[2])
+    ld = property(lambda s: s.base.shape[3])                                   # fp32 NHWC tensors only: channels per pixel
+    bs = property(lambda s: s.base[0].numel())                                 # elements per image of the underlying buffer
+    ptr = property(lambda s: s.base.data_ptr() + (s.c0 * s.H * s.W if s.base.dim() == 5 else s.c0) * s.base.element_size())
+    nbytes = property(lambda s: (s.base.numel() - (s.c0 * s.H * s.W if s.base.dim() == 5 else s.c0)) * s.base.element_size())
 
     def slice(self, c0, C):
         return ViewH(self.base, self.c0 + c0, C)
@@ -43,6 +46,22 @@ class ViewH:
     def images(self, lo, hi):
         """Sub-batch [lo, hi) (a view of the same memory)."""
         return ViewH(self.base[lo:hi], self.c0, self.C)
+
+    def nchw(self):
+        """float32 [N, C, H, W] copy (tests / debugging)."""
+        b = self.base[:, self.c0 // 16:(self.c0 + self.C) // 16]
+        return b.permute(0, 1, 4, 2, 3).reshape(self.N, self.C, self.H, self.W).float()
+
+
+def blocked_from_nchw(t, device=None):
+    """float [N, C, H, W] (C % 16 == 0) -> bf16 blocked [N, C/16, H, W, 16] (tests, boundary conversions)."""
+    N, C, H, W = t.shape
+    out = t.reshape(N, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous().to(BF16)
+    return out.to(device) if device is not None else out
+
+
+def empty_blocked(N, C, H, W, device, dtype=BF16):
+    return torch.empty((N, C // 16, H, W, 16), dtype=dtype, device=device)
 
 
 def _swizzle_rows(img, KC):
@@ -130,17 +149,19 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cou
     assert x.base.dtype == BF16 and x.C == pc.Cin
     Ho, Wo = (x.H - 1) // pc.stride + 1, (x.W - 1) // pc.stride + 1
     cout = pc.Cout if cout is None else cout
+    assert x.blocked
     if out_mode == OUT_F32_NCHW:
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (x.N, cout, Ho, Wo)
         yptr, ldy = out.data_ptr(), 0
     else:
         assert out.base.dtype == (BF16 if out_mode == OUT_BF16_NHWC else torch.float32)
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cout)
-        yptr, ldy = out.ptr, out.ld
+        yptr, ldy = (out.ptr, out.bs) if out_mode == OUT_BF16_NHWC else (out.ptr, out.ld)
+        assert out.blocked == (out_mode == OUT_BF16_NHWC)
     rp, ldr = None, 0
     if res is not None:
-        assert res.base.dtype == BF16 and (res.N, res.H, res.W, res.C) == (x.N, Ho, Wo, cout)
-        rp, ldr = res.ptr, res.ld
+        assert res.base.dtype == BF16 and res.blocked and (res.N, res.H, res.W, res.C) == (x.N, Ho, Wo, cout)
+        rp, ldr = res.ptr, res.bs
     meta = None
     if _lib.PROFILE is not None:
         M = x.N * Ho * Wo
@@ -148,7 +169,7 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cou
                 "exec_flops": pc.flops(M),
                 "bytes": 2.0 * (pc.Cin * x.N * x.H * x.W + pc.Cout * pc.Cin * pc.ks ** 2) + (2.0 if out_mode == 0 else 4.0) * cout * M}
     npf = pc.tile_npf(x.N, Ho, Wo)
-    _lib.call("sgta_conv_bf16", x.ptr, x.nbytes, x.ld, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
+    _lib.call("sgta_conv_bf16", x.ptr, x.nbytes, x.bs, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
               rp, ldr, yptr, ldy, x.N, x.H, x.W, pc.Cin, cout, pc.ks, pc.stride, pc.kc, pc.na, npf,
               pc.tile_log_tw(x.N, Ho, Wo, npf), act, out_mode, nsig, _stream(), meta=meta)
     return out
@@ -196,15 +217,15 @@ class PackedDCNBF16:
 def dcn_v2(x, om, pc, out, act=ACT_RELU):
     """x: ViewH bf16; om: ViewH float32 (>= 27 channels: the raw offset / mask conv output); out: ViewH bf16."""
     assert x.base.dtype == BF16 and om.base.dtype == torch.float32 and out.base.dtype == BF16
-    assert x.C == pc.Cin and out.C == pc.Cout and om.C >= 27 and x.c0 % 8 == 0
+    assert x.C == pc.Cin and out.C == pc.Cout and om.C >= 27 and x.blocked and out.blocked and not om.blocked
     assert (om.N, om.H, om.W) == (x.N, x.H, x.W) == (out.N, out.H, out.W)
     meta = None
     if _lib.PROFILE is not None:
         M = x.N * x.H * x.W
         meta = {"kernel": "dcn_bf16_kernel<%d>" % pc.na, "flops": pc.flops(M), "exec_flops": pc.flops(M),
                 "bytes": 2.0 * M * (pc.Cin + pc.Cout) + 4.0 * 27 * M + 2.0 * pc.Cout * pc.Cin * 9}
-    _lib.call("sgta_dcnv2_fwd_bf16", x.ptr, x.ld, om.ptr, om.ld, pc.wt.data_ptr(), pc.wt.numel() * 2,
-              pc.bias.data_ptr(), out.ptr, out.ld, x.N, x.H, x.W, pc.Cin, pc.Cout, pc.na,
+    _lib.call("sgta_dcnv2_fwd_bf16", x.ptr, x.bs, om.ptr, om.ld, pc.wt.data_ptr(), pc.wt.numel() * 2,
+              pc.bias.data_ptr(), out.ptr, out.bs, x.N, x.H, x.W, pc.Cin, pc.Cout, pc.na,
               pc.tile_log_tw(x.N, x.H, x.W), act, _stream(), meta=meta)
     return out
 
@@ -214,20 +235,20 @@ def stem(img, hm, pc16, out):
     pc16: ops.PackedC16 of the two stems (fp32 weights, f32 MFMA: the inputs are fp32 at the boundary)."""
     assert img.dtype == torch.float32 and hm.dtype == torch.float32 and img.is_contiguous() and hm.is_contiguous()
     B, _, H, W = img.shape
-    assert out.base.dtype == BF16 and (out.N, out.H, out.W, out.C) == (B, H, W, 16)
+    assert out.base.dtype == BF16 and out.blocked and (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
     meta = None
     if _lib.PROFILE is not None:
         M = B * H * W
         meta = {"kernel": "stem_c16_kernel<bf16>", "flops": pc16.flops(M), "exec_flops": pc16.flops(M) * 200.0 / 196.0,
                 "bytes": M * (16.0 + 32.0)}
     _lib.call("sgta_stem_bf16", img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pc16.wt.data_ptr(),
-              pc16.bias.data_ptr(), out.ptr, out.ld, B, H, W, _stream(), meta=meta)
+              pc16.bias.data_ptr(), out.ptr, 16, B, H, W, _stream(), meta=meta)
     return out
 
 
 def maxpool2(x, out):
     assert x.base.dtype == BF16 and out.base.dtype == BF16 and out.C == x.C
-    _lib.call("sgta_maxpool2_bf16", x.ptr, x.ld, out.ptr, out.ld, x.N, x.C, x.H, x.W, _stream())
+    _lib.call("sgta_maxpool2_bf16", x.ptr, x.bs, out.ptr, out.bs, x.N, x.C, x.H, x.W, _stream())
     return out
 
 
@@ -237,8 +258,8 @@ def pack_up_weight(w):
 
 
 def upsample_add(x, w_kkc, skip, out, f):
-    sp, lds = (skip.ptr, skip.ld) if skip is not None else (None, 0)
-    _lib.call("sgta_upsample_add_bf16", x.ptr, x.ld, w_kkc.data_ptr(), sp, lds, out.ptr, out.ld, x.N, x.C, x.H, x.W, f,
+    sp, lds = (skip.ptr, skip.bs) if skip is not None else (None, 0)
+    _lib.call("sgta_upsample_add_bf16", x.ptr, x.bs, w_kkc.data_ptr(), sp, lds, out.ptr, out.bs, x.N, x.C, x.H, x.W, f,
               _stream())
     return out
 
@@ -246,7 +267,7 @@ def upsample_add(x, w_kkc, skip, out, f):
 def window_gather(feats, fid, tok, col0=0):
     B, n = fid.shape
     assert tok.dtype == torch.float32 and tok.stride(-1) == 1
-    _lib.call("sgta_window_gather_bf16", feats.ptr, feats.ld, fid.data_ptr(), tok.data_ptr(), B, feats.C, feats.H,
+    _lib.call("sgta_window_gather_bf16", feats.ptr, feats.bs, fid.data_ptr(), tok.data_ptr(), B, feats.C, feats.H,
               feats.W, n, tok.stride(0), col0, _stream())
     return tok
 
@@ -255,5 +276,5 @@ def window_scatter(tok, fid, win, feats):
     B, n = fid.shape
     assert tok.dtype == torch.float32 and tok.stride(-1) == 1 and tok.shape[-1] == feats.C
     _lib.call("sgta_window_scatter_bf16", tok.data_ptr(), tok.stride(0), fid.data_ptr(), win.data_ptr(), feats.ptr,
-              feats.ld, B, feats.C, feats.H, feats.W, n, _stream())
+              feats.bs, B, feats.C, feats.H, feats.W, n, _stream())
     return feats

@@ -27,12 +27,20 @@ def bops():
 
 
 def nhwc(t_nchw):
-    """f32 NCHW (CPU) -> bf16 NHWC on the device."""
-    return t_nchw.permute(0, 2, 3, 1).contiguous().to(BF).to(DEV)
+    """f32 NCHW (CPU) -> bf16 blocked channels-last [N, C/16, H, W, 16] on the device."""
+    N, C, H, W = t_nchw.shape
+    return t_nchw.reshape(N, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous().to(BF).to(DEV)
 
 
-def nchw(t_nhwc):
-    return t_nhwc.float().cpu().permute(0, 3, 1, 2).contiguous()
+def nchw(t_blk):
+    """bf16 blocked [N, C/16, H, W, 16] -> f32 NCHW on the CPU."""
+    N, Cb, H, W, _ = t_blk.shape
+    return t_blk.float().cpu().permute(0, 1, 4, 2, 3).reshape(N, Cb * 16, H, W).contiguous()
+
+
+def blocked(N, C, H, W, fill=None):
+    t = torch.empty(N, C // 16, H, W, 16, dtype=BF, device=DEV)
+    return t.zero_() if fill is None else t.fill_(fill)
 
 
 def close(got, ref, rtol=8e-3, atol_rel=2e-3):
@@ -62,7 +70,7 @@ def test_conv_bf16(bops, N, cin, cout, H, W, ks, stride, act, res):
         ref = ref + r
     if act:
         ref = F.relu(ref)
-    out = torch.full((N, Ho, Wo, cout), 7.0, dtype=BF, device=DEV)
+    out = blocked(N, cout, Ho, Wo, 7.0)
     bops.conv(bops.ViewH(nhwc(x)), pc, bops.ViewH(out), act, res=bops.ViewH(nhwc(r)) if res else None)
     close(nchw(out), ref)
 
@@ -80,7 +88,7 @@ def test_conv_bf16_half_size_tiles(bops, N, cin, cout, H, W, ks):
     for npf in (1, 2):
         bops.FORCE_NPF = npf
         try:
-            out = torch.full((N, H, W, cout), 7.0, dtype=BF, device=DEV)
+            out = blocked(N, cout, H, W, 7.0)
             bops.conv(bops.ViewH(nhwc(x)), pc, bops.ViewH(out), 1)
         finally:
             bops.FORCE_NPF = None
@@ -99,11 +107,11 @@ def test_conv_bf16_channel_slices_and_fp32_outputs(bops):
     b = torch.randn(64, generator=g) * 0.1
     pc = bops.PackedConvBF16(w.to(DEV), b.to(DEV))
     xin = bops.ViewH(nhwc(big)).slice(32, 32)
-    outbuf = torch.zeros(N, H, W, 160, dtype=BF, device=DEV)
+    outbuf = blocked(N, 160, H, W)
     bops.conv(xin, pc, bops.ViewH(outbuf).slice(64, 64), 1)
     ref = F.relu(F.conv2d(big[:, 32:64], pc.w_ref.float().cpu(), b, padding=1))
-    close(nchw(outbuf[..., 64:128]), ref)
-    assert float(outbuf[..., :64].abs().max()) == 0 and float(outbuf[..., 128:].abs().max()) == 0
+    close(nchw(outbuf[:, 4:8]), ref)
+    assert float(outbuf[:, :4].abs().max()) == 0 and float(outbuf[:, 8:].abs().max()) == 0
     # fp32 NHWC (27 -> 32 channel offset conv)
     w27 = torch.randn(27, 32, 3, 3, generator=g) * 0.1
     b27 = torch.randn(27, generator=g) * 0.3
@@ -142,7 +150,7 @@ def test_dcn_bf16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
     ref = F.relu(ref + b.view(1, -1, 1, 1))
     om32 = torch.zeros(N, H, W, 32, device=DEV)
     om32[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
-    out = torch.full((N, H, W, cout), 5.0, dtype=BF, device=DEV)
+    out = blocked(N, cout, H, W, 5.0)
     bops.dcn_v2(bops.ViewH(nhwc(x)), bops.ViewH(om32), pc, bops.ViewH(out), 1)
     # the blended sample is rounded to bf16 before the product (the fp32 oracle keeps it in fp32): 2^-9 per sample
     close(nchw(out), ref, rtol=1e-2, atol_rel=4e-3)
@@ -150,19 +158,20 @@ def test_dcn_bf16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
 
 def test_elementwise_bf16(bops):
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(3, 24, 10, 14, generator=g).to(BF).float()
-    out = torch.zeros(3, 5, 7, 40, dtype=BF, device=DEV)
-    bops.maxpool2(bops.ViewH(nhwc(x)), bops.ViewH(out).slice(8, 24))
-    assert torch.equal(nchw(out[..., 8:32]), F.max_pool2d(x, 2))
+    x = torch.randn(3, 32, 10, 14, generator=g).to(BF).float()
+    out = blocked(3, 64, 5, 7)
+    bops.maxpool2(bops.ViewH(nhwc(x)), bops.ViewH(out).slice(16, 32))
+    assert torch.equal(nchw(out[:, 1:3]), F.max_pool2d(x, 2))
+    assert float(out[:, :1].abs().max()) == 0 and float(out[:, 3:].abs().max()) == 0
     for f in (2, 4):
-        w = torch.randn(24, 1, 2 * f, 2 * f, generator=g)
-        skip = torch.randn(3, 24, 10 * f, 14 * f, generator=g).to(BF).float()
-        ref = F.conv_transpose2d(x, w, stride=f, padding=f // 2, groups=24) + skip
-        o = torch.empty(3, 10 * f, 14 * f, 24, dtype=BF, device=DEV)
+        w = torch.randn(32, 1, 2 * f, 2 * f, generator=g)
+        skip = torch.randn(3, 32, 10 * f, 14 * f, generator=g).to(BF).float()
+        ref = F.conv_transpose2d(x, w, stride=f, padding=f // 2, groups=32) + skip
+        o = blocked(3, 32, 10 * f, 14 * f)
         bops.upsample_add(bops.ViewH(nhwc(x)), bops.pack_up_weight(w.to(DEV)), bops.ViewH(nhwc(skip)), bops.ViewH(o), f)
         close(nchw(o), ref, rtol=8e-3, atol_rel=2e-3)
     # window gather / ordered scatter
-    B, C, H, W, n = 3, 24, 10, 14, 20
+    B, C, H, W, n = 3, 32, 10, 14, 20
     fid = torch.randint(0, H * W, (B, n), generator=g)
     fid[0, 5] = fid[0, 2]                                  # duplicate: the LAST token wins
     win = torch.ones(B, n, dtype=torch.uint8)              # winners = tokens with no later duplicate (sgta_window_index)
@@ -171,7 +180,7 @@ def test_elementwise_bf16(bops):
             win[b, t_] = int(not bool((fid[b, t_ + 1:] == fid[b, t_]).any()))
     assert win[0, 2] == 0
     feats = bops.ViewH(nhwc(x))
-    tok = torch.zeros(B * n, 32, device=DEV)
+    tok = torch.zeros(B * n, 40, device=DEV)
     bops.window_gather(feats, fid.to(DEV), tok, col0=8)
     ref = torch.gather(x.reshape(B, C, -1), 2, fid.view(B, 1, n).expand(B, C, n)).permute(0, 2, 1).reshape(B * n, C)
     assert torch.equal(tok[:, 8:].cpu(), ref) and float(tok[:, :8].abs().max()) == 0
@@ -195,7 +204,7 @@ def test_stem_bf16(bops):
                   torch.randn(16, generator=g) * 0.1, torch.rand(16, generator=g) + 0.5)
     bi, bh = bn(), bn()
     pc = PackedC16(wi.to(DEV), tuple(t.to(DEV) for t in bi), wh.to(DEV), tuple(t.to(DEV) for t in bh))
-    out = torch.empty(B, H, W, 16, dtype=BF, device=DEV)
+    out = blocked(B, 16, H, W)
     bops.stem(img.to(DEV), hm.to(DEV), pc, bops.ViewH(out))
     ref = (F.relu(F.batch_norm(F.conv2d(img, wi, padding=3), bi[2], bi[3], bi[0], bi[1], False, 0.0, 1e-5)) +
            F.relu(F.batch_norm(F.conv2d(hm, wh, padding=3), bh[2], bh[3], bh[0], bh[1], False, 0.0, 1e-5)))

@@ -33,10 +33,10 @@ def dcn():
     g = torch.Generator().manual_seed(0)
     for (N, cin, cout, H, W) in ((32, 64, 64, 120, 160), (32, 128, 64, 60, 80), (32, 256, 64, 30, 40), (32, 128, 128, 60, 80),
                                  (32, 256, 256, 30, 40), (32, 512, 256, 15, 20)):
-        x = torch.randn(N, H, W, cin, generator=g).to(BF).to(DEV)
+        x = torch.randn(N, cin // 16, H, W, 16, generator=g).to(BF).to(DEV)
         w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
         pc = bops.PackedDCNBF16(w.to(DEV), torch.zeros(cout, device=DEV))
-        out = torch.empty(N, H, W, cout, dtype=BF, device=DEV)
+        out = torch.empty(N, cout // 16, H, W, 16, dtype=BF, device=DEV)
         for name, scale in (("zero", 0.0), ("s1", 1.0), ("s3", 3.0), ("s10", 10.0)):
             om = torch.zeros(N, H, W, 32, device=DEV)
             om[..., :27] = torch.randn(N, H, W, 27, generator=g).to(DEV) * scale
@@ -51,11 +51,11 @@ def conv():
               (64, 512, 512, 15, 20, 3, 1), (32, 64, 768, 120, 160, 3, 1), (32, 64, 32, 120, 160, 3, 1), (64, 128, 64, 120, 160, 1, 1),
               (64, 448, 128, 60, 80, 1, 1), (64, 896, 256, 30, 40, 1, 1), (64, 1280, 512, 15, 20, 1, 1), (64, 64, 128, 120, 160, 3, 2))
     for (N, cin, cout, H, W, ks, st) in shapes:
-        x = torch.randn(N, H, W, cin, generator=g).to(BF).to(DEV)
+        x = torch.randn(N, cin // 16, H, W, 16, generator=g).to(BF).to(DEV)
         w = torch.randn(cout, cin, ks, ks, generator=g) * 0.05
         pc = bops.PackedConvBF16(w.to(DEV), torch.zeros(cout, device=DEV), stride=st)
         Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
-        out = torch.empty(N, Ho, Wo, cout, dtype=BF, device=DEV)
+        out = torch.empty(N, cout // 16, Ho, Wo, 16, dtype=BF, device=DEV)
         for npf in ((1,) if st == 2 else (2, 1)):
             bops.FORCE_NPF = npf
             ms = timeit(lambda: bops.conv(bops.ViewH(x), pc, bops.ViewH(out), 1))
