@@ -350,6 +350,17 @@ int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, cons
 int sgta_stem_bf16(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt, const float* bias,
                    void* y, int ldy, int B, int H, int W, sgta_stream_t stream);
 
+/* The whole input stage in one kernel: both 7x7 stems, their sum (dla.py:259-270, :324-328) and level0 = conv3x3(16 -> 16)
+ * + BN + ReLU (dla.py:271-273) -- fp32 NCHW image [B,3,H,W] (img_bs elements per image) + prior map [B,1,H,W] in, bf16
+ * blocked level0 map [B][1][H][W][16] (y_bs elements per image) out; the stem map stays in LDS.  w_stem: bf16 A fragments
+ * [7 k-steps = ky][2: image stem, prior stem][64 lanes][8] of v_mfma_f32_16x16x32_bf16 (row m = lane & 15 carries channel
+ * 4*perm[m>>2] + (m&3), perm = {0,2,1,3}; element j of lane k-group g = lane >> 4 is tap kx = 2g + (j>>2) (kx = 7: zero),
+ * input channel j & 3 (0..2 image, 3 prior map; zero in the other stem's fragments)); b_stem f32 [32] (folded BN);
+ * w_l0: bf16 [5 k-steps][64 lanes][8]: tap 2s + (g>>1), input channels 8*(g&1)..+7; b_l0 f32 [16].  W % 4 == 0. */
+int sgta_stem_level0_bf16(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
+                          const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B, int H,
+                          int W, sgta_stream_t stream);
+
 /* MaxPool2d(2,2) (dla.py:218-220) on bf16 blocked maps. */
 int sgta_maxpool2_bf16(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, sgta_stream_t stream);
 

@@ -1,0 +1,201 @@
+// Fused input stage of the bf16 data path for gfx950: the two 7x7 stems and level0 in ONE kernel
+//
+//   s  = relu(bn(conv7x7(img))) + relu(bn(conv7x7(hm)))          (DLA.base_layer / pre_hm_layer and their sum:
+//   y0 = relu(bn(conv3x3(s)))                                      reference dla.py:259-270, :324-328; level0 :271-273)
+//
+// fp32 NCHW image [B,3,H,W] + prior map [B,1,H,W] in, bf16 blocked level0 map [B][1][H][W][16] out.  Un-fused, the 16-channel
+// stem map is written and read back at full resolution (2 x 32 bytes per pixel against 16 bytes of input) and the 7x7
+// products run on the f32 matrix pipe; here the stem of an 18x66-pixel region stays in LDS as bf16 (rounded exactly as
+// the un-fused path rounds it on its way to HBM) and both products run on v_mfma_f32_16x16x32_bf16:
+//
+//   stem    D[cout 16][pixel 16] += W[cout][k] * X[k][pixel],  k = (ky; kx 0..7, 4 channels): 7 k-steps of 32, the 8th tap
+//           carries zero weights.  The input window lies in LDS pixel-major ([row][col][image 3 + prior 1] bf16, 8 bytes per
+//           pixel), so a lane's 8 k (2 taps x 4 channels) are 16 contiguous, 8-byte-aligned bytes = one ds_read2_b64, no
+//           im2col copy (a DS access off its natural alignment is replayed at 64 cycles: a plane-major window whose
+//           fragments are 8 taps of one channel at 2-byte alignment ran 4x slower).  The two stems have separate ReLUs:
+//           two accumulators, the image stem's A fragments are zero on channel 3 and the prior stem's on channels 0..2
+//   level0  k = (tap, 16 channels): 5 k-steps of 2 taps; a pixel's fragment is one aligned ds_read_b128 of the stem region
+//           (two 16-byte halves per pixel, XOR-swizzled by bit 3 of the pixel index: conflict-free for 16 consecutive pixels)
+//
+// MFMA row m = 4 j + i carries output channel 4 perm[j] + i, perm = {0, 2, 1, 3}: after one v_permlane32_swap between two
+// pixel groups every lane holds 8 consecutive channels of ONE pixel = a 16-byte store (LDS and HBM alike).
+// The input image is rounded to bf16 once (2^-9 relative, like every other activation of this path); accumulation fp32.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct SlArgs {
+  const float* img; long img_bs;
+  const float* hm;  long hm_bs;
+  const bf16x8* w_stem;              // [7 k-steps (ky)][2: image stem, prior stem][64 lanes] A fragments
+  const float* b_stem;               // [32]: image stem 0..15, prior stem 16..31 (folded BN)
+  const bf16x8* w_l0;                // [5 k-steps][64 lanes]
+  const float* b_l0;                 // [16]
+  __bf16* y; long y_bs;
+  int B, H, W, n_ty, n_tx;
+};
+
+namespace sl {
+constexpr int TH = 16, TW = 64;                          // level0 pixels per work-group
+constexpr int WH = TH + 8, WW = TW + 8, WS = 80;         // input window rows / columns / row stride (pixels of 8 bytes)
+constexpr int WQ = WW / 4;                               // float4 loads per window row and channel
+constexpr int SH = TH + 2, SW = TW + 2, SPX = SH * SW;   // stem region
+constexpr int WIN_BYTES = WH * WS * 8;                   // 15,360
+constexpr int STEM_BYTES = SPX * 32;                     // 38,016
+constexpr int N_SPAIR = (SPX + 31) / 32;                 // pairs of 16-pixel groups of the stem region (38)
+}  // namespace sl
+
+__global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
+  using namespace sl;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[WIN_BYTES + STEM_BYTES];
+  unsigned char* const win = lds;
+  unsigned char* const stem = lds + WIN_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, kg = lane >> 4;
+  const int bid = blockIdx.x;
+  const int tx = bid % a.n_tx, ty = (bid / a.n_tx) % a.n_ty, b = bid / (a.n_tx * a.n_ty);
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int H = a.H, W = a.W;
+  const long HW = (long)H * W;
+
+  // ---- phase 1: fp32 window -> bf16 [row][col][4 channels] in LDS (zero outside the image = the 7x7 convs' padding) ----------
+  for (int e = tid; e < WH * WQ; e += 256) {
+    const int r = e / WQ, q = e - r * WQ;
+    const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+    f32x4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+      const float* src = a.img + (long)b * a.img_bs + (long)gy * W + gx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const f32x4*>(src + c * HW);
+      v[3] = *reinterpret_cast<const f32x4*>(a.hm + (long)b * a.hm_bs + (long)gy * W + gx);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<bf16x4*>(win + (r * WS + 4 * q + i) * 8) =
+          __builtin_convertvector(f32x4{v[0][i], v[1][i], v[2][i], v[3][i]}, bf16x4);
+  }
+  if (tid < 4 * WH)                                         // columns 72..79: read by the zero-weight 8th tap, must be finite
+    *reinterpret_cast<u32x4*>(win + ((tid >> 2) * WS + WW) * 8 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
+
+  // ---- weights and biases of this lane (A fragments: row m = lane & 15, k group = lane >> 4) -------------------------------
+  bf16x8 ws[7][2], wl[5];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    ws[s][0] = a.w_stem[(2 * s) * 64 + lane];
+    ws[s][1] = a.w_stem[(2 * s + 1) * 64 + lane];
+  }
+#pragma unroll
+  for (int s = 0; s < 5; ++s) wl[s] = a.w_l0[s * 64 + lane];
+  const int c4 = 4 * (((kg & 1) << 1) | (kg >> 1));        // first of this lane's 4 output channels (rows 4 kg .. 4 kg + 3)
+  const f32x4 bi = *reinterpret_cast<const f32x4*>(a.b_stem + c4);
+  const f32x4 bh = *reinterpret_cast<const f32x4*>(a.b_stem + 16 + c4);
+  const f32x4 bl = *reinterpret_cast<const f32x4*>(a.b_l0 + c4);
+
+  __syncthreads();
+
+  // ---- phase 2: stem of the (TH+2) x (TW+2) region -> bf16 in LDS ---------------------------------------------------------
+  for (int pr = wave; pr < N_SPAIR; pr += 4) {
+    int p[2], base[2];
+    bool inside[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      p[u] = (2 * pr + u) * 16 + n;
+      const int pc = p[u] < SPX ? p[u] : SPX - 1;
+      const int ry = pc / SW, rx = pc - ry * SW;
+      base[u] = (ry * WS + rx + 2 * kg) * 8;                              // taps kx = 2 kg, 2 kg + 1 of row ky = k-step
+      inside[u] = (unsigned)(y0 - 1 + ry) < (unsigned)H && (unsigned)(x0 - 1 + rx) < (unsigned)W;
+    }
+    f32x4 ai[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ah[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned char* src = win + base[u] + s * (WS * 8);
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 8);
+        const bf16x8 x = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+        ai[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[s][0], x, ai[u], 0, 0, 0);
+        ah[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[s][1], x, ah[u], 0, 0, 0);
+      }
+    u32x2 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        r[i] = fmaxf(ai[u][i] + bi[i], 0.0f) + fmaxf(ah[u][i] + bh[i], 0.0f);
+        if (!inside[u]) r[i] = 0.0f;                                      // level0's zero padding
+      }
+      v[u] = __builtin_bit_cast(u32x2, __builtin_convertvector(r, bf16x4));
+    }
+    const auto s0 = __builtin_amdgcn_permlane32_swap(v[0][0], v[1][0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(v[0][1], v[1][1], false, false);
+    const int pst = lane < 32 ? p[0] : p[1];
+    if (pst < SPX)
+      *reinterpret_cast<u32x4*>(stem + pst * 32 + (((kg & 1) ^ ((pst >> 3) & 1)) << 4)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+  }
+  __syncthreads();
+
+  // ---- phase 3: level0 (3x3, 16 -> 16) from the stem region, 16-byte stores of the blocked map ----------------------------
+  int toff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int t = 2 * s + (kg >> 1);
+    const int tt = t < 9 ? t : 0;
+    toff[s] = (tt / 3) * SW + tt % 3;
+  }
+  __bf16* const yb = a.y + (long)b * a.y_bs;
+#pragma unroll 2
+  for (int j = 0; j < (TH * TW / 32) / 4; ++j) {
+    const int pr = wave * ((TH * TW / 32) / 4) + j;
+    const int oy = pr >> 1, oxa = (pr & 1) * 32;                            // groups 2 pr, 2 pr + 1: columns oxa + 16 u + n
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int px = oy * SW + oxa + 16 * u + n + toff[s];
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(stem + px * 32 + (((kg & 1) ^ ((px >> 3) & 1)) << 4));
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], x, acc[u], 0, 0, 0);
+      }
+    u32x2 v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = fmaxf(acc[u][i] + bl[i], 0.0f);
+      v[u] = __builtin_bit_cast(u32x2, __builtin_convertvector(r, bf16x4));
+    }
+    const auto s0 = __builtin_amdgcn_permlane32_swap(v[0][0], v[1][0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(v[0][1], v[1][1], false, false);
+    const int gy = y0 + oy, gx = x0 + oxa + (lane < 32 ? 0 : 16) + n;
+    if (gy < H && gx < W)
+      *reinterpret_cast<u32x4*>(yb + ((long)gy * W + gx) * 16 + 8 * (kg & 1)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+  }
+}
+
+extern "C" int sgta_stem_level0_bf16(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
+                                     const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B,
+                                     int H, int W, hipStream_t st) {
+  if (!img || !hm || !w_stem || !b_stem || !w_l0 || !b_l0 || !y || B <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
+  // float4 window loads: rows and planes of both inputs must be 16-byte aligned
+  if (W % 4 || img_bs % 4 || hm_bs % 4 || ((uintptr_t)img & 15) || ((uintptr_t)hm & 15) || ((uintptr_t)y & 15) || y_bs % 8)
+    return SGTA_EBADARG;
+  if (((uintptr_t)w_stem & 15) || ((uintptr_t)w_l0 & 15) || ((uintptr_t)b_stem & 15) || ((uintptr_t)b_l0 & 15)) return SGTA_EBADARG;
+  SlArgs a{};
+  a.img = img; a.img_bs = img_bs; a.hm = hm; a.hm_bs = hm_bs;
+  a.w_stem = reinterpret_cast<const bf16x8*>(w_stem); a.b_stem = b_stem;
+  a.w_l0 = reinterpret_cast<const bf16x8*>(w_l0); a.b_l0 = b_l0;
+  a.y = reinterpret_cast<__bf16*>(y); a.y_bs = y_bs; a.B = B; a.H = H; a.W = W;
+  a.n_ty = cdiv(H, sl::TH); a.n_tx = cdiv(W, sl::TW);
+  const long blocks = (long)B * a.n_ty * a.n_tx;
+  if (blocks > 0x7fffffffL) return SGTA_EBADARG;
+  hipLaunchKernelGGL(stem_l0_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}

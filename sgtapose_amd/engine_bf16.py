@@ -20,6 +20,7 @@ from .ops_bf16 import BF16, PackedConvBF16, PackedDCNBF16, ViewH
 
 class EngineBF16(Engine):
     dtype = "bf16"
+    fuse_stem = True          # sgta_stem_level0_bf16 (bf16 MFMA, stem map in LDS) instead of the f32 stem kernel + level0 conv
 
     # ------------------------------------------------------------------------------------------
     def _pack(self, m):
@@ -28,6 +29,9 @@ class EngineBF16(Engine):
         P["stem.c16"] = ops.PackedC16(b.pre_img_layer[0].weight, _bn_tuple(b.pre_img_layer[1]),
                                        b.pre_hm_layer[0].weight, _bn_tuple(b.pre_hm_layer[1]))
         P["level0"] = PackedConvBF16(b.level0[0].weight, None, _bn_tuple(b.level0[1]))
+        P["stem_l0"] = bops.PackedStemL0BF16(b.pre_img_layer[0].weight, _bn_tuple(b.pre_img_layer[1]),
+                                             b.pre_hm_layer[0].weight, _bn_tuple(b.pre_hm_layer[1]),
+                                             b.level0[0].weight, _bn_tuple(b.level0[1]))
         P["level1"] = PackedConvBF16(b.level1[0].weight, None, _bn_tuple(b.level1[1]), stride=2)
 
         def pack_tree(node, name):
@@ -127,11 +131,16 @@ class EngineBF16(Engine):
         B, _, H, W = frames[-1][0].shape
         N = len(frames) * B
         P = self.P
-        s = self.hbuf("stem", N, H, W, 16)
-        for k, (img, hm) in enumerate(frames):
-            bops.stem(img, hm, P["stem.c16"], s.images(k * B, (k + 1) * B))
         lv = [self.hbuf("l0", N, H, W, 16)]
-        bops.conv(s, P["level0"], lv[0], ACT_RELU)
+        if self.fuse_stem:
+            # stems + level0 in one kernel: the 16-channel stem map never leaves the chip
+            for k, (img, hm) in enumerate(frames):
+                bops.stem_level0(img, hm, P["stem_l0"], lv[0].images(k * B, (k + 1) * B))
+        else:
+            s = self.hbuf("stem", N, H, W, 16)
+            for k, (img, hm) in enumerate(frames):
+                bops.stem(img, hm, P["stem.c16"], s.images(k * B, (k + 1) * B))
+            bops.conv(s, P["level0"], lv[0], ACT_RELU)
         if after_level:
             after_level(0, lv[0])
         lv.append(self.hbuf("l1", N, H // 2, W // 2, 32))

@@ -246,6 +246,67 @@ def stem(img, hm, pc16, out):
     return out
 
 
+_ROW_PERM = (0, 2, 1, 3)      # MFMA row m = 4 j + i carries output channel 4 * _ROW_PERM[j] + i (stem_l0_bf16.hip)
+
+
+class PackedStemL0BF16:
+    """bf16 A fragments of sgta_stem_level0_bf16: the two 7x7 stems (image 3 -> 16, prior map 1 -> 16) and level0
+    (3x3, 16 -> 16), BatchNorm folded.  ``w_img_ref`` / ``w_hm_ref`` / ``w_l0_ref`` are the rounded weights (tests)."""
+
+    def __init__(self, w_img, bn_img, w_hm, bn_hm, w_l0, bn_l0):
+        wi, bi = fold_bn(w_img.detach().float(), None, bn_img)
+        wh, bh = fold_bn(w_hm.detach().float(), None, bn_hm)
+        wl, bl = fold_bn(w_l0.detach().float(), None, bn_l0)
+        assert tuple(wi.shape) == (16, 3, 7, 7) and tuple(wh.shape) == (16, 1, 7, 7) and tuple(wl.shape) == (16, 16, 3, 3)
+        dev = wi.device
+        lane = torch.arange(64, device=dev)
+        m, g = lane & 15, lane >> 4
+        cout = 4 * torch.tensor(_ROW_PERM, device=dev)[m >> 2] + (m & 3)                   # [64]
+        # stem A fragments [ky][image / prior stem][lane][j]: tap kx = 2 g + (j >> 2), channel j & 3 (3 = the prior map)
+        ws = torch.zeros(7, 2, 64, 8, device=dev)
+        wi8 = torch.cat([wi, wi.new_zeros(16, 3, 7, 1)], 3)                                # kx 0..7 (the 8th tap is zero)
+        wh8 = torch.cat([wh, wh.new_zeros(16, 1, 7, 1)], 3)
+        for ky in range(7):
+            for j in range(8):
+                kx, ch = 2 * g + (j >> 2), j & 3
+                if ch < 3:
+                    ws[ky, 0, :, j] = wi8[cout, ch, ky, kx]
+                else:
+                    ws[ky, 1, :, j] = wh8[cout, 0, ky, kx]
+        wl9 = torch.cat([wl.reshape(16, 16, 9), wl.new_zeros(16, 16, 1)], 2)              # [co, ci, tap 0..9]
+        wf = torch.zeros(5, 64, 8, device=dev)
+        for s in range(5):
+            t = 2 * s + (g >> 1)
+            for j in range(8):
+                wf[s, :, j] = wl9[cout, 8 * (g & 1) + j, t]
+        self.w_stem = ws.to(BF16).contiguous()
+        self.w_l0 = wf.to(BF16).contiguous()
+        self.b_stem = torch.cat([bi, bh]).float().contiguous()
+        self.b_l0 = bl.float().contiguous()
+        self.w_img_ref, self.w_hm_ref, self.w_l0_ref = wi.to(BF16), wh.to(BF16), wl.to(BF16)
+        self.b_img_ref, self.b_hm_ref = bi, bh
+
+    @staticmethod
+    def flops(M):
+        return 2.0 * M * 16 * (4 * 49 + 16 * 9)
+
+
+def stem_level0(img, hm, pk, out):
+    """out (ViewH bf16, 16 channels) = level0(relu(bn(conv7x7(img))) + relu(bn(conv7x7(hm)))) in one kernel; img / hm: f32
+    NCHW tensors at the API boundary."""
+    assert img.dtype == torch.float32 and hm.dtype == torch.float32 and img.is_contiguous() and hm.is_contiguous()
+    B, _, H, W = img.shape
+    assert out.base.dtype == BF16 and out.blocked and (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
+    meta = None
+    if _lib.PROFILE is not None:
+        M = B * H * W
+        meta = {"kernel": "stem_l0_bf16_kernel", "flops": pk.flops(M), "exec_flops": 2.0 * M * 16 * (14 * 32 + 5 * 32),
+                "bytes": M * (16.0 + 32.0)}
+    _lib.call("sgta_stem_level0_bf16", img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pk.w_stem.data_ptr(),
+              pk.b_stem.data_ptr(), pk.w_l0.data_ptr(), pk.b_l0.data_ptr(), out.ptr, out.bs, B, H, W, _stream(), meta=meta)
+    return out
+
+
 def maxpool2(x, out):
     assert x.base.dtype == BF16 and out.base.dtype == BF16 and out.C == x.C
     _lib.call("sgta_maxpool2_bf16", x.ptr, x.bs, out.ptr, out.bs, x.N, x.C, x.H, x.W, _stream())

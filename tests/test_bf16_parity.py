@@ -211,6 +211,32 @@ def test_stem_bf16(bops):
     close(nchw(out), ref, rtol=5e-3, atol_rel=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 48, 136), (3, 16, 64), (1, 37, 68)])
+def test_stem_level0_fused_bf16(bops, B, H, W):
+    """sgta_stem_level0_bf16 (both 7x7 stems + sum + level0 in one kernel, bf16 MFMA) against fp32 torch on the SAME
+    bf16-rounded image / weights with the stem map rounded to bf16 where the kernel rounds it (tiles with borders on
+    every side, maps that are not multiples of the 16x64 tile)."""
+    g = torch.Generator().manual_seed(H + W)
+    img = (torch.rand(B, 3, H, W, generator=g) * 4 - 2)
+    hm = torch.rand(B, 1, H, W, generator=g)
+    wi, wh = torch.randn(16, 3, 7, 7, generator=g) * 0.1, torch.randn(16, 1, 7, 7, generator=g) * 0.15
+    wl = torch.randn(16, 16, 3, 3, generator=g) * 0.12
+    bn = lambda: (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1,      # noqa: E731
+                  torch.randn(16, generator=g) * 0.1, torch.rand(16, generator=g) + 0.5)
+    bi, bh, bl = bn(), bn(), bn()
+    dv = lambda t: tuple(x.to(DEV) for x in t)                                               # noqa: E731
+    pk = bops.PackedStemL0BF16(wi.to(DEV), dv(bi), wh.to(DEV), dv(bh), wl.to(DEV), dv(bl))
+    out = blocked(B, 16, H, W, 9.0)
+    bops.stem_level0(img.to(DEV), hm.to(DEV), pk, bops.ViewH(out))
+    r = lambda t: t.to(BF).float()                                                           # noqa: E731
+    s = (F.relu(F.conv2d(r(img), pk.w_img_ref.float().cpu(), pk.b_img_ref.cpu(), padding=3)) +
+         F.relu(F.conv2d(r(hm), pk.w_hm_ref.float().cpu(), pk.b_hm_ref.cpu(), padding=3)))
+    ref = F.relu(F.conv2d(r(s), pk.w_l0_ref.float().cpu(), pk.b_l0.cpu(), padding=1))
+    # the stem map is rounded to bf16 in both; a last-bit flip of a stem value (fp32 summation order) moves an output by
+    # 2^-9 |s| |w|: tolerance as for the other bf16 convs
+    close(nchw(out), ref, rtol=8e-3, atol_rel=3e-3)
+
+
 # ---- network level ---------------------------------------------------------------------------------------------------
 BF16_LOGIT_TOL = 6e-2      # max |logit_bf16 - logit_fp32 oracle| asserted for hm / reg / tracking (measured ~2e-2, see DESIGN.md)
 BF16_LOGIT_MEAN_TOL = 8e-3
