@@ -333,6 +333,17 @@ int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void* wt, long 
                    int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
                    sgta_stream_t stream);
 
+/* The head branches (base_model.py:121-135: conv3x3 -> ReLU -> conv1x1 per head) in ONE kernel: hidden = relu(conv3x3(x) + b1)
+ * with the branches' 3x3 convs concatenated (Chid channels; w1 / b1 in sgta_conv_bf16's layout for na = 4) is rounded to bf16
+ * in registers and multiplied by the block-diagonal 1x1 weights of all branches (<= 16 output rows) -- the hidden tensor never
+ * exists in memory.  out_i: f32 NCHW [N, c_i, H, W] (c_i = 0: unused), sigmoid on rows < nsig.  w2: bf16 A fragments
+ * [Chid/128][4][2][64 lanes][8] of the second v_mfma_f32_32x32x16_bf16: element j of lane (m = lane & 31, h = lane >> 5) in
+ * k-step t of 32-channel block i of tile ct is W2[m][128 ct + 32 i + 8 (2t + (j >> 2)) + 4h + (j & 3)]; b2 f32 [16]. */
+int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
+                    const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0, int c1,
+                    int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                    sgta_stream_t stream);
+
 /* DeformConv (dla.py:538-550) = lbin/DCNv2 modulated deformable 3x3 conv + folded BN + ReLU on bf16 blocked maps -- the
  * ``sgta_dcnv2_fwd_bf16`` of SURVEY.md section 8b.  om: f32 NHWC [N,H,W,ldo], channels 0..17 = (dy, dx) per tap,
  * 18..26 = mask logits (raw conv_offset_mask output, sigmoid applied here); sampling coordinates and bilinear /

@@ -29,6 +29,11 @@ struct CbArgs {
   const __bf16* res; long res_bs;                // residual, bf16 blocked at the output resolution (or null)
   void* y;          long y_bs;                   // bf16 blocked (elements per image) / fp32 NHWC (channels per pixel) / fp32 NCHW (unused)
   int N, H, W, Ho, Wo, Cout, nchunks, n_ct, n_rt, n_xt, log_tw, act, out_mode, nsig;
+  // fused heads (FUSE = 1): second product W2 [<= 16 outputs] x relu(conv + bias) over ALL n_ct channel tiles of the work-group
+  const void* w2;                                // bf16 A fragments [n_ct][NA][2 k-steps][64 lanes][8]
+  const float* b2;                               // [16]
+  float* out[4];                                 // f32 NCHW per head
+  int hs[5];                                     // first output row of head i (hs[n_heads..4] = total)
 };
 
 template <int KS, int S, int KC, int NPF>
@@ -46,7 +51,12 @@ struct CbGeom {
 
 __device__ __forceinline__ float cb_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
-template <int KS, int S, int KC, int NPF, int NA>
+// FUSE = 1 (the three head branches, base_model.py:121-135: conv3x3 -> ReLU -> conv1x1 each, their 3x3 convs concatenated to
+// one Cin -> n_ct*TC product): the work-group walks ALL channel tiles of its positions; after the last chunk of a tile the
+// hidden activations relu(acc + bias) are rounded to bf16 IN REGISTERS -- accumulator registers 8t..8t+7 of a lane are
+// exactly the B operand (k = 8h + j) of a second v_mfma_f32_32x32x16_bf16 whose k order the packed W2 follows -- and
+// multiplied by the (block-diagonal) 1x1 weights of the heads: the hidden tensor never exists in memory.
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int TC = NA * 32, TAPS = G::TAPS, KSTEPS = G::KSTEPS, P = G::P, ROWB = G::ROWB, LOG_R = G::LOG_R;
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   int pt, ct;
-  xcd_remap(blockIdx.x, a.n_ct, pt, ct);
+  xcd_remap(blockIdx.x, FUSE ? 1 : a.n_ct, pt, ct);
   if (pt >= a.n_rt * a.n_xt) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,9 +119,9 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), (short)0, (int)a.wt_bytes, 0x00020000);
 #endif
-  // DMA instruction j (0 .. NDMA-1) of chunk kc into stage st: window rounds first, then the weight image
+  // DMA instruction j (0 .. NDMA-1) of chunk kc (weight image wi) into stage st: window rounds first, then the weight image
   constexpr int NDMA = G::WROUNDS + AROUNDS;
-  auto dma_one = [&](int j, int kc, int st) {
+  auto dma_one = [&](int j, int kc, int wi, int st) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned char* wdst = smem + st * STAGE + wave * 1024;
     if (j < G::WROUNDS)
@@ -119,12 +129,12 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
                                                kc * (KC / 16) * a.H * a.W * 32, 0, 0);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wdst + G::WIN_BYTES + (j - G::WROUNDS) * 8192), 16,
-                                               aoffw[j >= G::WROUNDS ? j - G::WROUNDS : 0], (ct * a.nchunks + kc) * WIMG, 0, 0);
+                                               aoffw[j >= G::WROUNDS ? j - G::WROUNDS : 0], wi * WIMG, 0, 0);
 #endif
   };
-  auto stage = [&](int kc, int st) {
+  auto stage = [&](int kc, int wi, int st) {
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) dma_one(j, kc, st);
+    for (int j = 0; j < NDMA; ++j) dma_one(j, kc, wi, st);
   };
 
   // ---- per-lane output positions and LDS fragment addresses -----------------------------------------------------
@@ -159,12 +169,24 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
 
-  stage(0, 0);
-  for (int kc = 0; kc < a.nchunks; ++kc) {
-    const int st = kc & 1;
+  f32x16 acc2[FUSE ? NPF : 1];
+  if (FUSE) {
+#pragma unroll
+    for (int f = 0; f < NPF; ++f)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc2[f][q] = 0.0f;
+  }
+  // FUSE: one flat sequence of (channel tile, chunk) steps; the window of chunk kc is fetched again for every tile (L2)
+  const int n_it = FUSE ? a.n_ct * a.nchunks : a.nchunks;
+  const int wi0 = FUSE ? 0 : ct * a.nchunks;
+  int kc = 0, ctl = 0;
+  stage(0, wi0, 0);
+  for (int it = 0; it < n_it; ++it) {
+    const int st = it & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const bool more = kc + 1 < a.nchunks;          // the next chunk's DMA is issued piece by piece between the MFMA groups below
+    const bool more = it + 1 < n_it;               // the next chunk's DMA is issued piece by piece between the MFMA groups below
+    const int nkc = kc + 1 < a.nchunks ? kc + 1 : 0;
     const unsigned char* Ws = smem + st * STAGE;
     const unsigned char* As = Ws + G::WIN_BYTES;
     // software pipeline over the k-steps of the chunk: the fragments of step k + 1 are requested before the MFMAs of step
@@ -194,9 +216,57 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       if (more) {
 #pragma unroll
         for (int d = 0; d < DPK; ++d)
-          if (k * DPK + d < NDMA) dma_one(k * DPK + d, kc + 1, st ^ 1);
+          if (k * DPK + d < NDMA) dma_one(k * DPK + d, nkc, wi0 + it + 1, st ^ 1);
       }
     }
+    if (FUSE && nkc == 0) {
+      // ---- channel tile ctl is complete: hidden = relu(acc + bias) -> bf16 -> second product, accumulators cleared ------
+      const bf16x8* w2 = reinterpret_cast<const bf16x8*>(a.w2) + (long)ctl * NA * 2 * 64 + lane;
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const bf16x8 a2 = w2[(i * 2 + t) * 64];
+          const float* bp = a.bias + ctl * TC + i * 32 + 16 * t + 4 * h;          // rows (j & 3) + 8 (2t + (j >> 2)) + 4h
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 8);
+#pragma unroll
+          for (int f = 0; f < NPF; ++f) {
+            typedef float f32x8 __attribute__((ext_vector_type(8)));
+            f32x8 hv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = fmaxf(acc[i][f][8 * t + j] + (j < 4 ? b0[j & 3] : b1[j & 3]), 0.0f);
+            acc2[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_convertvector(hv, bf16x8), acc2[f], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int f = 0; f < NPF; ++f)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
+      ++ctl;
+    }
+    kc = nkc;
+  }
+
+  if (FUSE) {
+    // ---- heads epilogue: rows m = (q & 3) + 8 (q >> 2) + 4h < 16 of acc2 -> f32 NCHW of the head that owns row m -----------
+    const long HWo = (long)a.Ho * a.Wo;
+#pragma unroll
+    for (int f = 0; f < NPF; ++f) {
+      if (prem[f] < 0) continue;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int m = (q & 3) + 8 * (q >> 2) + 4 * h;
+        if (m >= a.hs[4]) continue;
+        const int hd = (m >= a.hs[1]) + (m >= a.hs[2]) + (m >= a.hs[3]);
+        const int c = m - a.hs[hd], nc = a.hs[hd + 1] - a.hs[hd];
+        float v = acc2[f][q] + a.b2[m];
+        if (m < a.nsig) v = cb_sigmoid(v);
+        a.out[hd][((long)pn[f] * nc + c) * HWo + prem[f]] = v;
+      }
+    }
+    return;
   }
 
   // ---- epilogue: C/D layout col = lane & 31 (position), row = (q & 3) + 8 (q >> 2) + 4 h (output channel) ----------
@@ -269,13 +339,13 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   }
 }
 
-template <int KS, int S, int KC, int NPF, int NA>
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0>
 static int cb_launch(CbArgs& a, hipStream_t st) {
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int WIMG = KS * KS * NA * 32 * KC * 2;
   constexpr int LDS = 2 * (G::WIN_BYTES + ((WIMG + 8191) / 8192) * 8192);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA>;
+  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE>;
   static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
   bool& done = attr_by_dev[sgta_device_slot()];
   if (!done) {
@@ -284,7 +354,7 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
     done = true;
   }
   const int n_pt = a.n_rt * a.n_xt;
-  const int grid = cdiv(n_pt, 8) * 8 * a.n_ct;
+  const int grid = cdiv(n_pt, 8) * 8 * (FUSE ? 1 : a.n_ct);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
@@ -338,5 +408,34 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
     if (na == 2) return cb_launch<1, 1, 32, 1, 2>(a, st);
     if (na == 4) return cb_launch<1, 1, 32, 1, 4>(a, st);
   }
+  return SGTA_EBADARG;
+}
+
+// The three head branches in one kernel (base_model.py:121-135): hidden = relu(conv3x3(x) + b1) with the branches' 3x3 convs
+// concatenated (Chid = n_ct * 128 channels, w1 / b1 as sgta_conv_bf16 with na = 4), out = W2 . hidden + b2 with the
+// block-diagonal 1x1 weights of all branches (<= 16 output rows in total), written as f32 NCHW per head: out_i [N, c_i, H, W],
+// sigmoid on rows < nsig.  w2: bf16 A fragments [Chid/128][4][2][64 lanes][8] of the second v_mfma_f32_32x32x16_bf16: lane
+// (m = lane & 31, h = lane >> 5), element j of k-step t of 32-channel block i holds W2[m][128 ct + 32 i + 8 (2t + (j >> 2)) +
+// 4h + (j & 3)] (zero for m >= the number of rows).  npf / log_tw as sgta_conv_bf16.  Cin % 16 == 0, Chid % 128 == 0.
+extern "C" int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
+                               const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0,
+                               int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                               hipStream_t st) {
+  if (!x || !w1 || !b1 || !w2 || !b2 || !out0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Chid <= 0) return SGTA_EBADARG;
+  if (x_bytes <= 0 || x_bytes > 0x7fffffffL || w1_bytes <= 0 || w1_bytes > 0x7fffffffL) return SGTA_EBADARG;
+  if (Cin % 16 || Chid % 128 || (x_bs % 16) || ((uintptr_t)x & 15) || ((uintptr_t)w2 & 15) || log_tw < 3 || log_tw > 6) return SGTA_EBADARG;
+  if (c0 <= 0 || c1 < 0 || c2 < 0 || c3 < 0 || c0 + c1 + c2 + c3 > 16) return SGTA_EBADARG;
+  if ((c1 > 0 && !out1) || (c2 > 0 && !out2) || (c3 > 0 && !out3)) return SGTA_EBADARG;
+  CbArgs a{};
+  a.x = x; a.x_bytes = x_bytes; a.x_bs = x_bs; a.wt = w1; a.wt_bytes = w1_bytes; a.bias = b1;
+  a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = Chid; a.nchunks = Cin / 16; a.n_ct = Chid / 128;
+  a.log_tw = log_tw; a.act = 1; a.out_mode = 1; a.nsig = nsig;
+  a.w2 = w2; a.b2 = b2; a.out[0] = out0; a.out[1] = out1; a.out[2] = out2; a.out[3] = out3;
+  a.hs[0] = 0; a.hs[1] = c0; a.hs[2] = c0 + c1; a.hs[3] = c0 + c1 + c2; a.hs[4] = c0 + c1 + c2 + c3;
+  const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
+  a.n_rt = cdiv((long)N * (H + 1), TR);
+  a.n_xt = cdiv(W, TW);
+  if (npf == 2) return cb_launch<3, 1, 16, 2, 4, 1>(a, st);
+  if (npf == 1) return cb_launch<3, 1, 16, 1, 4, 1>(a, st);
   return SGTA_EBADARG;
 }

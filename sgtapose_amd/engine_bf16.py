@@ -20,6 +20,7 @@ from .ops_bf16 import BF16, PackedConvBF16, PackedDCNBF16, ViewH
 
 class EngineBF16(Engine):
     dtype = "bf16"
+    fuse_heads = True         # sgta_heads_bf16: the 3x3 -> ReLU -> 1x1 branches in one kernel, no hidden tensor in memory
     fuse_stem = True          # sgta_stem_level0_bf16 (bf16 MFMA, stem map in LDS) instead of the f32 stem kernel + level0 conv
 
     # ------------------------------------------------------------------------------------------
@@ -74,6 +75,11 @@ class EngineBF16(Engine):
         self.head_hidden = [getattr(m, h)[0].out_channels for h in self.head_names]
         for h in self.head_names:
             P["heads.2." + h] = PackedConvBF16(getattr(m, h)[2].weight, getattr(m, h)[2].bias)
+        try:
+            P["heads.fused"] = bops.PackedHeadsBF16([(getattr(m, h)[0].weight, getattr(m, h)[0].bias, getattr(m, h)[2].weight,
+                                                      getattr(m, h)[2].bias) for h in self.head_names])
+        except _lib.SgtaHipError:
+            P["heads.fused"] = None               # unusual head configuration: 3x3 conv + three 1x1 kernels
         self.P = P
 
     def hbuf(self, name, n, h, w, c, dtype=BF16):
@@ -239,6 +245,13 @@ class EngineBF16(Engine):
 
     def heads(self, feat, hm_act=ACT_NONE, static=False):
         B, h, w = feat.N, feat.H, feat.W
+        pk = self.P.get("heads.fused") if self.fuse_heads else None
+        if pk is not None:
+            outs = [self.buf("out_" + n, (B, r, h, w)) if static else torch.empty((B, r, h, w), dtype=torch.float32, device=self.dev)
+                    for n, r in zip(self.head_names, pk.rows)]
+            nsig = pk.rows[0] if (self.head_names[0] == "hm" and hm_act == ops.ACT_SIGMOID) else 0
+            bops.heads_fused(feat, pk, outs, nsig)
+            return dict(zip(self.head_names, outs))
         hidden = self.hbuf("head_hidden", B, h, w, sum(self.head_hidden))
         bops.conv(feat, self.P["heads.0"], hidden, ACT_RELU)
         out, off = {}, 0

@@ -175,6 +175,62 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cou
     return out
 
 
+class PackedHeadsBF16:
+    """Weights of sgta_heads_bf16: ``pc1`` = PackedConvBF16 of the concatenated 3x3 convs (na = 4) and the block-diagonal 1x1
+    weights of all heads as A fragments of the second product.  heads: [(w3x3, b3x3, w1x1, b1x1), ...] in output order."""
+
+    def __init__(self, heads):
+        w1 = torch.cat([h[0].detach().float() for h in heads], 0)
+        b1 = torch.cat([h[1].detach().float() for h in heads], 0)
+        self.pc1 = PackedConvBF16(w1, b1)
+        chid = w1.shape[0]
+        self.rows = [h[2].shape[0] for h in heads]
+        if self.pc1.na != 4 or chid % 128 or len(heads) > 4 or sum(self.rows) > 16:
+            raise _lib.SgtaHipError("fused heads need Chid % 128 == 0, <= 4 heads and <= 16 output rows")
+        dev = w1.device
+        W2 = torch.zeros(32, chid, device=dev)
+        b2 = torch.zeros(16, device=dev)
+        r0 = c0 = 0
+        for (w3, _, w, b) in heads:
+            n, ch = w.shape[0], w3.shape[0]
+            W2[r0:r0 + n, c0:c0 + ch] = w.detach().float().reshape(n, ch)
+            b2[r0:r0 + n] = b.detach().float()
+            r0, c0 = r0 + n, c0 + ch
+        lane = torch.arange(64, device=dev)
+        m, h = lane & 31, lane >> 5
+        j = torch.arange(8, device=dev)
+        frag = torch.zeros(chid // 128, 4, 2, 64, 8, device=dev)
+        for ct in range(chid // 128):
+            for i in range(4):
+                for t in range(2):
+                    ch = 128 * ct + 32 * i + 8 * (2 * t + (j[None, :] >> 2)) + 4 * h[:, None] + (j[None, :] & 3)     # [64, 8]
+                    frag[ct, i, t] = W2[m[:, None].expand(64, 8), ch]
+        self.w2 = frag.to(BF16).contiguous()
+        self.b2 = b2.contiguous()
+        self.w2_ref = W2[:16].to(BF16)            # tests: [16, Chid] rounded
+        self.Chid = chid
+
+
+def heads_fused(x, pk, outs, nsig=0):
+    """outs[i] (f32 NCHW [N, rows_i, H, W]) = head i of the fused head kernel on x (ViewH bf16)."""
+    assert x.blocked and x.base.dtype == BF16 and x.C == pk.pc1.Cin and len(outs) == len(pk.rows)
+    for o, n in zip(outs, pk.rows):
+        assert o.dtype == torch.float32 and o.is_contiguous() and tuple(o.shape) == (x.N, n, x.H, x.W)
+    meta = None
+    if _lib.PROFILE is not None:
+        M = x.N * x.H * x.W
+        fl = pk.pc1.flops(M) + 2.0 * M * pk.Chid * sum(pk.rows)
+        meta = {"kernel": "conv_bf16_kernel<3,1,4,heads>", "flops": fl, "exec_flops": pk.pc1.flops(M) + 2.0 * M * pk.Chid * 32,
+                "bytes": 2.0 * pk.pc1.Cin * M + 4.0 * sum(pk.rows) * M + 2.0 * pk.Chid * pk.pc1.Cin * 9}
+    npf = 2 if FORCE_NPF is None else FORCE_NPF
+    ptrs = [o.data_ptr() for o in outs] + [None] * (4 - len(outs))
+    rows = list(pk.rows) + [0] * (4 - len(outs))
+    _lib.call("sgta_heads_bf16", x.ptr, x.nbytes, x.bs, pk.pc1.wt.data_ptr(), pk.pc1.wt.numel() * 2, pk.pc1.bias.data_ptr(),
+              pk.w2.data_ptr(), pk.b2.data_ptr(), *ptrs, *rows, x.N, x.H, x.W, pk.pc1.Cin, pk.Chid, npf,
+              pk.pc1.tile_log_tw(x.N, x.H, x.W, npf), nsig, _stream(), meta=meta)
+    return outs
+
+
 class PackedDCNBF16:
     """bf16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][Cin/16][tap][TC][16] (the 3x3
     layout of sgta_conv_bf16), BN folded."""

@@ -237,6 +237,33 @@ def test_stem_level0_fused_bf16(bops, B, H, W):
     close(nchw(out), ref, rtol=8e-3, atol_rel=3e-3)
 
 
+@pytest.mark.parametrize("N,H,W,npf", [(2, 14, 22, 2), (1, 30, 40, 1), (3, 8, 64, 2)])
+def test_heads_fused_bf16(bops, N, H, W, npf):
+    """sgta_heads_bf16 (3x3 -> ReLU -> 1x1 of the three heads, hidden tensor in registers) against fp32 torch on the same
+    bf16-rounded weights with the hidden activations rounded to bf16; sigmoid on the hm rows."""
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, 64, H, W, generator=g).to(BF).float()
+    heads, ref = [], []
+    for n in (7, 2, 2):
+        w3 = torch.randn(256, 64, 3, 3, generator=g) * 0.06
+        b3 = torch.randn(256, generator=g) * 0.1
+        w1 = torch.randn(n, 256, 1, 1, generator=g) * 0.1
+        b1 = torch.randn(n, generator=g)
+        heads.append(tuple(t.to(DEV) for t in (w3, b3, w1, b1)))
+        hid = F.relu(F.conv2d(x, w3.to(BF).float(), b3, padding=1)).to(BF).float()
+        ref.append(F.conv2d(hid, w1.to(BF).float(), b1))
+    ref[0] = torch.sigmoid(ref[0])
+    pk = bops.PackedHeadsBF16(heads)
+    outs = [torch.full((N, n, H, W), 5.0, device=DEV) for n in (7, 2, 2)]
+    bops.FORCE_NPF = npf
+    try:
+        bops.heads_fused(bops.ViewH(nhwc(x)), pk, outs, nsig=7)
+    finally:
+        bops.FORCE_NPF = None
+    for o, r in zip(outs, ref):
+        assert torch.allclose(o.cpu(), r, atol=4e-3, rtol=2e-3), float((o.cpu() - r).abs().max())
+
+
 # ---- network level ---------------------------------------------------------------------------------------------------
 BF16_LOGIT_TOL = 6e-2      # max |logit_bf16 - logit_fp32 oracle| asserted for hm / reg / tracking (measured ~2e-2, see DESIGN.md)
 BF16_LOGIT_MEAN_TOL = 8e-3
