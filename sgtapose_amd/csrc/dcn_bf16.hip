@@ -7,17 +7,18 @@
 // the bf16 MFMA B operand of that (pixel, tap, 8 channels) in registers -- the [9*Cin, H*W] column buffer of the
 // reference never exists.  A = the bf16 weights, staged per 16-channel chunk ([tap][TC][16], XOR-swizzled rows) by 16-byte
 // buffer LDS-DMA, shared by the 8 waves of the work-group; every gathered sample feeds all TC = 64 / 128 output
-// channels of the work-group.  Accumulation fp32 on v_mfma_f32_32x32x16_bf16.
+// channels of the work-group.  Accumulation fp32 on v_mfma_f32_32x32x16_f16 (weights and blended samples fp16, see below).
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct DbArgs {
   const __bf16* x;  long x_bs;  long x_bytes;    // bf16 blocked input [N][Cb][H][W][16] (pointer at the view's first block), elements per image, extent
   const float* om;  int ldo;                     // f32 NHWC offsets / mask logits [N,H,W,ldo]: ldo >= 28, ldo % 4 == 0 (read as 7 x 16 bytes)
-  const void* wt;   long wt_bytes;               // packed [n_ct][Cin/16][9][TC][16] bf16, swizzled
+  const void* wt;   long wt_bytes;               // packed [n_ct][Cin/16][9][TC][16] FP16, swizzled
   const float* bias;                             // [n_ct * TC]
   __bf16* y;        long y_bs;                   // bf16 blocked output, elements per image
   int N, H, W, Cin, Cout, ngroups, n_ct, n_rt, n_xt, log_tw, act;
@@ -40,8 +41,12 @@ __device__ __forceinline__ int db_div(int v, unsigned m) { return (int)__umulhi(
 // VALU issue (one wave64 instruction per ~4 cycles and SIMD) is what bounds the gather: 96 instructions per wave, tap and 8
 // channels, a third of them bf16 -> f32 conversions of window elements that are each used ~36 times.  So the staged
 // window is converted ONCE per chunk, in place, to fp16 (exact for bf16 values with |x| in [6e-5, 65504]; larger values
-// are clamped to +-65504, smaller ones flush towards zero) and the blend is four v_fma_mix_f32 per channel (fp32
-// weight x fp16 corner + fp32 sum, the fp16 -> fp32 widening inside the instruction): 32 + 4 (pack) instead of 68.
+// are clamped to +-65504, smaller ones flush towards zero), the main product runs on v_mfma_f32_32x32x16_F16 with the
+// weights packed as fp16 (11 significand bits: closer to the fp32 weights than bf16), and the blend is PACKED fp16
+// arithmetic on channel pairs -- one v_pk_mul_f16 + three v_pk_fma_f16 per pair with the per-(pixel, tap, corner) weight
+// (bilinear x validity x sigmoid(mask), computed in fp32, rounded once to fp16) broadcast to both halves: 16 instructions per
+// tap and 8 channels, and the result IS the MFMA B operand (the fp32 form took 32 v_fma_mix_f32 + 4 conversions, the first
+// one 68).  The blend rounds to 11 bits three times where the un-deformed conv path rounds its activations to 8 (bf16).
 #define DB_R 6
 #ifndef DB_ABLATE
 #define DB_ABLATE 0          // tools only (tools/dcn_ablate.sh): 1 no MFMA, 2 no blend, 3 no corner reads, 4 no conversion, 5 no DMA
@@ -52,7 +57,7 @@ __device__ __forceinline__ int db_div(int v, unsigned m) { return (int)__umulhi(
 // run under the others' gather -- with one 8-wave double-buffered work-group per CU those phases were 45 % of a
 // 64-channel layer's time (25 k cycles per work-group against 7.5 k per chunk).
 template <int NA>
-__global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
+__global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   constexpr int TC = NA * 32, TP = 128, ROWB = 32, NT = 256;
   constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + NT * 16 - 1) / (NT * 16);
   constexpr int WS_MAX = (4 + 2 * DB_R + 1) * (32 + 2 * DB_R + 1);      // 4 x 32 tiles have the largest window (765 slots)
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
   constexpr bool PRE = NA <= 2;                  // registers allow keeping all 36 corner LDS addresses (else 9 slots + on-the-fly)
   int sbase[9];                                  // window slot of the sample's top-left corner (y0, x0)
   unsigned caddr[PRE ? 9 : 1][4];
-  float cw[9][4];
+  f16x2 cw[9][4];                                // corner weights, fp16, broadcast to both halves of a channel pair
   unsigned inmask = 0;                           // bit t: all four corners of tap t lie inside the staged window
   {
     // the pixel's 27 offset / mask values: one 128-byte row, fetched as 7 x 16 bytes
@@ -147,10 +152,12 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
       const float ly = py - fy, lx = px - fx, hy = 1.0f - ly, hx = 1.0f - lx;
       const int y0 = (int)fy, x0 = (int)fx;
       const bool oy0 = y0 >= 0, oy1 = y0 + 1 <= H - 1, ox0 = x0 >= 0, ox1 = x0 + 1 <= W - 1;
-      cw[t][0] = (inside && oy0 && ox0) ? hy * hx * m : 0.0f;
-      cw[t][1] = (inside && oy0 && ox1) ? hy * lx * m : 0.0f;
-      cw[t][2] = (inside && oy1 && ox0) ? ly * hx * m : 0.0f;
-      cw[t][3] = (inside && oy1 && ox1) ? ly * lx * m : 0.0f;
+      const float w0 = (inside && oy0 && ox0) ? hy * hx * m : 0.0f, w1 = (inside && oy0 && ox1) ? hy * lx * m : 0.0f;
+      const float w2 = (inside && oy1 && ox0) ? ly * hx * m : 0.0f, w3 = (inside && oy1 && ox1) ? ly * lx * m : 0.0f;
+      cw[t][0] = f16x2{(_Float16)w0, (_Float16)w0};
+      cw[t][1] = f16x2{(_Float16)w1, (_Float16)w1};
+      cw[t][2] = f16x2{(_Float16)w2, (_Float16)w2};
+      cw[t][3] = f16x2{(_Float16)w3, (_Float16)w3};
       // window coordinates of (y0, x0); the +1 corners need wr + 1 < WR and wc + 1 < WC.  A sample outside the image has
       // all-zero weights: it is pointed at slot 0 and counts as inside.
       const int wr = n * H + y0 - R0, wc = x0 - X0;
@@ -188,14 +195,14 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
       s0 = __builtin_fmaf(w4[2], (float)cv[2][j], s0);
       v[j] = __builtin_fmaf(w4[3], (float)cv[3][j], s0);
     }
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-    const bf16x8 bfr = __builtin_convertvector(vv, bf16x8);
-    bf16x8 af[NA];
+    f16x8 bfr;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
+    for (int j = 0; j < 8; ++j) bfr[j] = (_Float16)fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+    f16x8 af[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
+    for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const f16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfr, acc[i], 0, 0, 0);
   };
 
   // wave-uniform choice for the whole tile: every sample of every lane inside the staged window -> LDS gathers; otherwise
@@ -244,24 +251,24 @@ __global__ __launch_bounds__(256) void dcn_bf16_kernel(DbArgs a) {
             cv[k] = *reinterpret_cast<const f16x8*>(Ws + slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
           }
         }
-        bf16x8 af[NA];
+        f16x8 af[NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
-        float v[8];
+        for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const f16x8*>(As + (t * TC + i * 32) * ROWB + aaddr);
+        f16x8 bfr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                // four v_fma_mix_f32: fp32 weight x fp16 corner + fp32 sum
-          float s0 = __builtin_fmaf(cw[t][0], (float)cv[0][j], 0.0f);
-          s0 = __builtin_fmaf(cw[t][1], (float)cv[1][j], s0);
-          s0 = __builtin_fmaf(cw[t][2], (float)cv[2][j], s0);
-          v[j] = __builtin_fmaf(cw[t][3], (float)cv[3][j], s0);
+        for (int j = 0; j < 4; ++j) {                // channel pair j: v_pk_mul_f16 + 3 v_pk_fma_f16
+          f16x2 s0 = cw[t][0] * f16x2{cv[0][2 * j], cv[0][2 * j + 1]};
+          s0 = __builtin_elementwise_fma(cw[t][1], f16x2{cv[1][2 * j], cv[1][2 * j + 1]}, s0);
+          s0 = __builtin_elementwise_fma(cw[t][2], f16x2{cv[2][2 * j], cv[2][2 * j + 1]}, s0);
+          s0 = __builtin_elementwise_fma(cw[t][3], f16x2{cv[3][2 * j], cv[3][2 * j + 1]}, s0);
+          bfr[2 * j] = s0[0];
+          bfr[2 * j + 1] = s0[1];
         }
-        typedef float f32x8 __attribute__((ext_vector_type(8)));
-        const f32x8 vv = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-        const bf16x8 bfr = DB_ABLATE == 2 ? __builtin_bit_cast(bf16x8, cv[0]) : __builtin_convertvector(vv, bf16x8);
+        if (DB_ABLATE == 2) bfr = cv[0];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
           if (DB_ABLATE == 1) acc[i][t] += (float)bfr[i] + (float)af[i][t & 7];
-          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr, acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfr, acc[i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);           // one tap's reads in flight at a time (registers: 3 work-groups per CU)
       }

@@ -80,7 +80,7 @@ def _swizzle_rows(img, KC):
 class PackedConvBF16:
     """bf16 weights of one conv in the [cout tile][chunk][tap][TC][KC] LDS-image layout of sgta_conv_bf16, BN folded."""
 
-    def __init__(self, weight, bias=None, bn=None, stride=1, cout_pad_to=None):
+    def __init__(self, weight, bias=None, bn=None, stride=1, cout_pad_to=None, na=None):
         w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
         co, ci, ks, _ = w.shape
         if cout_pad_to is not None and cout_pad_to > co:                 # e.g. the 27-channel offset / mask conv -> 32
@@ -92,7 +92,8 @@ class PackedConvBF16:
         self.kc = 16 if ks == 3 else 32
         if ci % self.kc:
             raise _lib.SgtaHipError("bf16 conv needs Cin %% %d == 0, got %d" % (self.kc, ci))
-        na = 1 if co <= 32 else (2 if co <= 64 else 4)
+        if na is None:
+            na = 1 if co <= 32 else (2 if co <= 64 else 4)
         if stride == 2:
             na = min(na, 2)
         self.na, self.TC = na, 32 * na
@@ -232,7 +233,7 @@ def heads_fused(x, pk, outs, nsig=0):
 
 
 class PackedDCNBF16:
-    """bf16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][Cin/16][tap][TC][16] (the 3x3
+    """fp16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][Cin/16][tap][TC][16] (the 3x3
     layout of sgta_conv_bf16), BN folded."""
 
     def __init__(self, weight, bias=None, bn=None):
@@ -249,11 +250,12 @@ class PackedDCNBF16:
         wp = w.new_zeros(n_ct * self.TC, ci, 9)
         wp[:co] = w.reshape(co, ci, 9)
         img = wp.view(n_ct, self.TC, nch, 16, 9).permute(0, 2, 4, 1, 3).contiguous()      # [ct][chunk][tap][TC][16]
-        self.wt = _swizzle_rows(img, 16).to(BF16).contiguous()
+        # fp16 weights (v_mfma_f32_32x32x16_f16: the blended samples are fp16, dcn_bf16.hip), clamped to the fp16 range
+        self.wt = _swizzle_rows(img, 16).clamp(-65504.0, 65504.0).to(torch.float16).contiguous()
         bb = b.new_zeros(n_ct * self.TC)
         bb[:co] = b
         self.bias = bb.float().contiguous()
-        self.w_ref = w.to(BF16)
+        self.w_ref = w.clamp(-65504.0, 65504.0).to(torch.float16)
 
     def tile_log_tw(self, N, H, W):
         tp = 128                                   # 4 waves x 32 pixels (dcn_bf16.hip); window of <= 765 slots: TW <= 32

@@ -53,7 +53,7 @@ def conv():
     for (N, cin, cout, H, W, ks, st) in shapes:
         x = torch.randn(N, cin // 16, H, W, 16, generator=g).to(BF).to(DEV)
         w = torch.randn(cout, cin, ks, ks, generator=g) * 0.05
-        pc = bops.PackedConvBF16(w.to(DEV), torch.zeros(cout, device=DEV), stride=st)
+        pc = bops.PackedConvBF16(w.to(DEV), torch.zeros(cout, device=DEV), stride=st, na=(int(os.environ['NA']) if 'NA' in os.environ else None))
         Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
         out = torch.empty(N, cout // 16, Ho, Wo, 16, dtype=BF, device=DEV)
         for npf in ((1,) if st == 2 else (2, 1)):
