@@ -390,6 +390,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
+    enq = time.perf_counter() - t0                  # host time to ENQUEUE the K steps (the launches are asynchronous)
     barrier()
     el = time.perf_counter() - t0
     ranks_seen = 1
@@ -413,6 +414,7 @@ def main():
         "unit": "frame-windows/s" if seq else ("frame-triples/s" if three else "frame-pairs/s"),
         "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * el / args.steps, 3),
+        "host_enqueue_ms_per_step": round(1e3 * enq / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": cfg_name + ": batch=%d 2-frame %dx%d synthetic pairs per GPU, %s random-init (seeded), "

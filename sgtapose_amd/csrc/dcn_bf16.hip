@@ -48,6 +48,9 @@ __device__ __forceinline__ int db_div(int v, unsigned m) { return (int)__umulhi(
 // tap and 8 channels, and the result IS the MFMA B operand (the fp32 form took 32 v_fma_mix_f32 + 4 conversions, the first
 // one 68).  The blend rounds to 11 bits three times where the un-deformed conv path rounds its activations to 8 (bf16).
 #define DB_R 6
+#ifndef DB_SCHED
+#define DB_SCHED 1
+#endif
 #ifndef DB_ABLATE
 #define DB_ABLATE 0          // tools only (tools/dcn_ablate.sh): 1 no MFMA, 2 no blend, 3 no corner reads, 4 no conversion, 5 no DMA
 #endif
@@ -62,6 +65,10 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + NT * 16 - 1) / (NT * 16);
   constexpr int WS_MAX = (4 + 2 * DB_R + 1) * (32 + 2 * DB_R + 1);      // 4 x 32 tiles have the largest window (765 slots)
   constexpr int WROUNDS = (WS_MAX * 2 + NT - 1) / NT, WIN_BYTES = WROUNDS * NT * 16;
+  // the window is stored as two planes (channel halves) of 16-byte slots: the regular pattern (consecutive pixels ->
+  // consecutive slots) reads 16 lanes x 16 contiguous bytes (conflict-free without an XOR swizzle), and a sample's four
+  // corners are base + {0, 16, WC*16, WC*16 + 16}: one address register per tap
+  constexpr int WPL = WROUNDS * NT / 2;
   constexpr int STAGE = WIN_BYTES + AROUNDS * NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -83,13 +90,13 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
 #pragma unroll
   for (int t = 0; t < WROUNDS; ++t) {
     const int pi = t * NT + tid;
-    const int slot = pi >> 1, pp = pi & 1;
+    const int pp = pi >= WPL ? 1 : 0, slot = pi - pp * WPL;      // planar window: 8-channel half pp of every slot, then the other
     unsigned off = 0x80000000u;
     if (slot < WS) {
       const int wr = db_div(slot, mwc), wc = slot - wr * WC;
       const int Rs = R0 + wr, x = X0 + wc;
       if (Rs >= 0 && Rs < a.N * H && (unsigned)x < (unsigned)W) {
-        const int piece = pp ^ ((slot >> 3) & 1);
+        const int piece = pp;
         const int ni = db_div(Rs, a.mH), yi = Rs - ni * H;
         off = (unsigned)(((long)ni * a.x_bs + ((long)yi * W + x) * 16 + piece * 8) * 2);
       }
@@ -129,9 +136,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   const int n = db_div(Rp, a.mH), yp = Rp - n * H;
   const bool okp = n < a.N && xp < W;
   const long pix = okp ? (long)Rp * W + xp : -1;
-  constexpr bool PRE = NA <= 2;                  // registers allow keeping all 36 corner LDS addresses (else 9 slots + on-the-fly)
-  int sbase[9];                                  // window slot of the sample's top-left corner (y0, x0)
-  unsigned caddr[PRE ? 9 : 1][4];
+  int sbase[9];                                  // LDS byte offset of the sample's top-left corner (y0, x0), this lane's channel half
   f16x2 cw[9][4];                                // corner weights, fp16, broadcast to both halves of a channel pair
   unsigned inmask = 0;                           // bit t: all four corners of tap t lie inside the staged window
   {
@@ -162,14 +167,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
       // all-zero weights: it is pointed at slot 0 and counts as inside.
       const int wr = n * H + y0 - R0, wc = x0 - X0;
       const bool in = !inside || (wr >= 0 && wr + 1 < WR && wc >= 0 && wc + 1 < WC);
-      sbase[t] = (inside && in) ? wr * WC + wc : 0;
-      if (PRE) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int slot = sbase[t] + (k & 1) + (k >> 1) * WC;
-          caddr[PRE ? t : 0][k] = (unsigned)(slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
-        }
-      }
+      sbase[t] = ((inside && in) ? wr * WC + wc : 0) * 16 + h * (WPL * 16);
       inmask |= (in ? 1u : 0u) << t;
     }
   }
@@ -215,11 +213,16 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
 #pragma unroll
     for (int t = 0; t < WROUNDS; ++t) {
       unsigned char* pp = Wbuf + (t * NT + tid) * 16;
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(pp);
-      f16x8 hv;
+      // bf16 -> f32 is a shift / mask of the packed pair; v_cvt_pkrtz_f16_f32 converts two values per instruction, exactly
+      // (8 significant bits fit fp16's 11) and, rounding toward zero, saturates |x| > 65504 to +-65504 instead of infinity
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 b = *reinterpret_cast<const u32x4*>(pp);
+      u32x4 hv;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)fminf(fmaxf((float)b[j], -65504.0f), 65504.0f);
-      *reinterpret_cast<f16x8*>(pp) = hv;
+      for (int j = 0; j < 4; ++j)
+        hv[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__builtin_bit_cast(float, b[j] << 16),
+                                                                       __builtin_bit_cast(float, b[j] & 0xffff0000u)));
+      *reinterpret_cast<u32x4*>(pp) = hv;
     }
   };
   unsigned char* const Ws = smem;
@@ -236,20 +239,20 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
       __builtin_amdgcn_s_barrier();                // window (converted) + weights of chunk kc complete for all waves
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
+        // (requesting tap t + 1's corner runs before tap t's blend -- a two-deep software pipeline -- measured no gain on the
+        // 64-channel form and costs the 128-channel form 24 spilled registers: LDS latency is not what the taps wait for)
         f16x8 cv[4];
-        int sb = sbase[t];
-        if (!PRE) asm volatile("" : "+v"(sb));       // opaque: the corner addresses are recomputed per chunk, not kept in registers
+        const unsigned char* c0 = Ws + sbase[t];
+        const unsigned char* c1 = c0 + WC * 16;        // next window row
+        if (DB_ABLATE == 3) {
+          const _Float16 cst = (_Float16)(float)(sbase[t] & 7);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int slot = sb + (k & 1) + (k >> 1) * WC;
-          if (PRE) {
-            cv[k] = *reinterpret_cast<const f16x8*>(Ws + caddr[PRE ? t : 0][k]);
-          } else if (DB_ABLATE == 3) {
-            const _Float16 cst = (_Float16)(float)(slot & 7);
-            cv[k] = f16x8{cst, cst, cst, cst, cst, cst, cst, cst};
-          } else {
-            cv[k] = *reinterpret_cast<const f16x8*>(Ws + slot * ROWB + ((h ^ ((slot >> 3) & 1)) << 4));
-          }
+          for (int k = 0; k < 4; ++k) cv[k] = f16x8{cst, cst, cst, cst, cst, cst, cst, cst};
+        } else {
+          cv[0] = *reinterpret_cast<const f16x8*>(c0);
+          cv[1] = *reinterpret_cast<const f16x8*>(c0 + 16);
+          cv[2] = *reinterpret_cast<const f16x8*>(c1);
+          cv[3] = *reinterpret_cast<const f16x8*>(c1 + 16);
         }
         f16x8 af[NA];
 #pragma unroll
@@ -270,7 +273,9 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
           if (DB_ABLATE == 1) acc[i][t] += (float)bfr[i] + (float)af[i][t & 7];
           else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bfr, acc[i], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);           // one tap's reads in flight at a time (registers: 3 work-groups per CU)
+#if DB_SCHED
+        __builtin_amdgcn_sched_barrier(0);           // one tap's reads in flight at a time (without it the compiler's order is 3-10 % slower)
+#endif
       }
     }
   } else {

@@ -236,14 +236,14 @@ class PackedDCNBF16:
     """fp16 weights of one DCN main product in sgta_dcnv2_fwd_bf16's layout [cout tile][Cin/16][tap][TC][16] (the 3x3
     layout of sgta_conv_bf16), BN folded."""
 
-    def __init__(self, weight, bias=None, bn=None):
+    def __init__(self, weight, bias=None, bn=None, na=None):
         w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
         co, ci, ks, _ = w.shape
         assert ks == 3
         if ci % 16 or co % 8:
             raise _lib.SgtaHipError("bf16 DCN needs Cin %% 16 == 0 and Cout %% 8 == 0, got %d -> %d" % (ci, co))
         self.Cout, self.Cin = co, ci
-        self.na = 2 if co <= 64 else 4
+        self.na = (2 if co <= 64 else 4) if na is None else na
         self.TC = 32 * self.na
         n_ct = -(-co // self.TC)
         nch = ci // 16

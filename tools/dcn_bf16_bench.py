@@ -35,7 +35,7 @@ def dcn():
                                  (32, 256, 256, 30, 40), (32, 512, 256, 15, 20)):
         x = torch.randn(N, cin // 16, H, W, 16, generator=g).to(BF).to(DEV)
         w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
-        pc = bops.PackedDCNBF16(w.to(DEV), torch.zeros(cout, device=DEV))
+        pc = bops.PackedDCNBF16(w.to(DEV), torch.zeros(cout, device=DEV), na=(int(os.environ['NA']) if 'NA' in os.environ else None))
         out = torch.empty(N, cout // 16, H, W, 16, dtype=BF, device=DEV)
         for name, scale in (("zero", 0.0), ("s1", 1.0), ("s3", 3.0), ("s10", 10.0)):
             om = torch.zeros(N, H, W, 32, device=DEV)
