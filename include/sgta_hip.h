@@ -351,10 +351,13 @@ int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const void* w1, long
  * ldo >= 28 and ldo % 4 == 0 (a pixel's 27 values are fetched as 7 x 16 bytes).  The sampling neighbourhood of a tile is
  * staged in LDS (offsets up to +-6 pixels; beyond that a wave falls back to gathers from global memory, same arithmetic),
  * converted once per 16-channel chunk to fp16 and blended by v_fma_mix_f32.
- * wt: [Cout tile][Cin/16][9][32*na][16] bf16 swizzled (the 3x3 layout of sgta_conv_bf16); Cin % 16 == 0; na in {2,4}; log_tw 3..5. */
+ * wt: [Cout tile][Cin/16][9][32*na][16] bf16 swizzled (the 3x3 layout of sgta_conv_bf16); Cin % 16 == 0; na in {2,4}; margin 6 (samples
+ * up to +-6 pixels from the tile are gathered from the staged window; log_tw 3..5) or 10 (+-10 pixels plus patch slots for the
+ * samples beyond; log_tw 3..4) -- speed only, the result does not depend on it; wt is FP16 (the main product runs on
+ * v_mfma_f32_32x32x16_f16 with the blended samples in fp16). */
 int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
                         const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
-                        int na, int log_tw, int act, sgta_stream_t stream);
+                        int na, int log_tw, int margin, int act, sgta_stream_t stream);
 
 /* fused 7x7 stems (dla.py:259-270, :324-328): fp32 NCHW image [B,3,H,W] + prior map [B,1,H,W] in, bf16 [B,H,W,ldy]
  * (16 channels; ldy = 16 is the one-block blocked layout [B][1][H][W][16]) out; weights / bias as sgta_conv_c16_f32 mode 1. */

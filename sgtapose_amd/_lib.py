@@ -46,7 +46,7 @@ SIGNATURES = {
     "sgta_render_priors": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_post_process": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "sgta_conv_bf16": [_p, _l, _l, _p, _l, _p, _p, _l, _p, _l] + [_i] * 14 + [_p],
-    "sgta_dcnv2_fwd_bf16": [_p, _l, _p, _i, _p, _l, _p, _p, _l] + [_i] * 8 + [_p],
+    "sgta_dcnv2_fwd_bf16": [_p, _l, _p, _i, _p, _l, _p, _p, _l] + [_i] * 9 + [_p],
     "sgta_stem_bf16": [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _p],
     "sgta_heads_bf16": [_p, _l, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p],
     "sgta_stem_level0_bf16": [_p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],

@@ -47,7 +47,6 @@ __device__ __forceinline__ int db_div(int v, unsigned m) { return (int)__umulhi(
 // (bilinear x validity x sigmoid(mask), computed in fp32, rounded once to fp16) broadcast to both halves: 16 instructions per
 // tap and 8 channels, and the result IS the MFMA B operand (the fp32 form took 32 v_fma_mix_f32 + 4 conversions, the first
 // one 68).  The blend rounds to 11 bits three times where the un-deformed conv path rounds its activations to 8 (bf16).
-#define DB_R 6
 #ifndef DB_SCHED
 #define DB_SCHED 1
 #endif
@@ -59,17 +58,38 @@ __device__ __forceinline__ int db_div(int v, unsigned m) { return (int)__umulhi(
 // to three work-groups share a CU and one's prologue (27 offset loads, 9 x sampling parameters), DMA waits and epilogue
 // run under the others' gather -- with one 8-wave double-buffered work-group per CU those phases were 45 % of a
 // 64-channel layer's time (25 k cycles per work-group against 7.5 k per chunk).
-template <int NA>
+//
+// Margin R and far samples.  R = 6 (PR = 0): the 120x160 layers, whose offsets stay within a few pixels.  R = 10 with PR = 4
+// PATCH ROWS (the deep levels: on the benched network 8-18 % of their samples lie more than 6 pixels out, 0.1-1.4 % more than
+// 10): a sample whose 2x2 corner block leaves even the wider window gets a patch -- a 2x2 block of slots in PR extra window
+// rows under the regular ones.  The owner lane takes a patch index from an LDS counter and writes the four global pixel
+// offsets into a small LDS table; the DMA lanes that own those slots read their source offsets from the table, so the
+// patch pixels arrive with every chunk's window like any other slot, are converted with it, and the gather reads them
+// through the same base + {0, 16, WC*16, WC*16 + 16} addressing.  Only a tile with more far samples than patch blocks
+// (PR/2 * WC/2 = 28 / 36) falls back to the global-memory path, wave by wave.
+template <int R, int PR>
+struct DbGeom {
+  static constexpr int NT = 256;
+  static constexpr int ws(int tr, int tw) { return (tr + 2 * R + 1 + PR) * (tw + 2 * R + 1); }
+  static constexpr int mx(int a, int b) { return a > b ? a : b; }
+  // R = 6: tiles 4x32, 8x16, 16x8; R = 10: 8x16, 16x8 (a 4x32 tile would need a 53-column window)
+  static constexpr int WS_MAX = R <= 6 ? mx(ws(4, 32), mx(ws(8, 16), ws(16, 8))) : mx(ws(8, 16), ws(16, 8));
+  static constexpr int WROUNDS = (WS_MAX * 2 + NT - 1) / NT, WIN_BYTES = WROUNDS * NT * 16;
+  static constexpr int PT_MAX = PR * (16 + 2 * R + 1);                  // patch-table entries (slots of the patch rows)
+  static constexpr int AUX_BYTES = PR ? (PT_MAX * 4 + 16 + 15) / 16 * 16 : 0;
+};
+
+template <int NA, int R, int PR>
 __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
+  using G = DbGeom<R, PR>;
   constexpr int TC = NA * 32, TP = 128, ROWB = 32, NT = 256;
   constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + NT * 16 - 1) / (NT * 16);
-  constexpr int WS_MAX = (4 + 2 * DB_R + 1) * (32 + 2 * DB_R + 1);      // 4 x 32 tiles have the largest window (765 slots)
-  constexpr int WROUNDS = (WS_MAX * 2 + NT - 1) / NT, WIN_BYTES = WROUNDS * NT * 16;
+  constexpr int WROUNDS = G::WROUNDS, WIN_BYTES = G::WIN_BYTES;
   // the window is stored as two planes (channel halves) of 16-byte slots: the regular pattern (consecutive pixels ->
   // consecutive slots) reads 16 lanes x 16 contiguous bytes (conflict-free without an XOR swizzle), and a sample's four
   // corners are base + {0, 16, WC*16, WC*16 + 16}: one address register per tap
   constexpr int WPL = WROUNDS * NT / 2;
-  constexpr int STAGE = WIN_BYTES + AROUNDS * NT * 16;
+  constexpr int STAGE = WIN_BYTES + AROUNDS * NT * 16;      // + G::AUX_BYTES of patch table behind it
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   int pt, ct;
@@ -79,11 +99,18 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int TW = 1 << a.log_tw, TR = TP >> a.log_tw;
-  const int WC = TW + 2 * DB_R + 1, WR = TR + 2 * DB_R + 1, WS = WR * WC;
+  const int WC = TW + 2 * R + 1, WR = TR + 2 * R + 1, WS = WR * WC;
   const int rt = pt / a.n_xt, xt = pt - rt * a.n_xt;                    // (scalar division: once per work-group)
   const int H = a.H, W = a.W;
-  const int R0 = rt * TR - DB_R, X0 = xt * TW - DB_R;                   // stacked row / column of window slot (0, 0)
+  const int R0 = rt * TR - R, X0 = xt * TW - R;                         // stacked row / column of window slot (0, 0)
   const unsigned mwc = a.mWC[a.log_tw - 3];
+  unsigned* const ptab = reinterpret_cast<unsigned*>(smem + STAGE);     // [PR * WC] global offsets of the patch slots, then the counter
+  unsigned* const pcnt = ptab + G::PT_MAX;
+  if (PR) {
+    for (int i = tid; i < PR * WC; i += NT) ptab[i] = 0x80000000u;      // unused patch slots: zeros
+    if (tid == 0) *pcnt = 0u;
+    __syncthreads();
+  }
 
   // ---- per-lane DMA offsets (chunk-invariant): window slots in stacked-row space (N*H rows), weight image -------------
   unsigned woff[WROUNDS];
@@ -166,12 +193,60 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
       // window coordinates of (y0, x0); the +1 corners need wr + 1 < WR and wc + 1 < WC.  A sample outside the image has
       // all-zero weights: it is pointed at slot 0 and counts as inside.
       const int wr = n * H + y0 - R0, wc = x0 - X0;
-      const bool in = !inside || (wr >= 0 && wr + 1 < WR && wc >= 0 && wc + 1 < WC);
-      sbase[t] = ((inside && in) ? wr * WC + wc : 0) * 16 + h * (WPL * 16);
+      bool in = !inside || (wr >= 0 && wr + 1 < WR && wc >= 0 && wc + 1 < WC);
+      int slot0 = (inside && in) ? wr * WC + wc : 0;
+      if (PR) {
+        // far sample: the lower lane half takes a patch block and publishes its four source pixels; both halves address it
+        int pid = -1;
+        if (!in && h == 0) pid = (int)__hip_atomic_fetch_add(pcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pid = __shfl(pid, r);
+        const int ppr = WC >> 1;                       // patch blocks per pair of patch rows
+        if (pid >= 0 && pid < (PR / 2) * ppr) {
+          const int prow = pid / ppr, pcol = pid - prow * ppr;
+          slot0 = (WR + 2 * prow) * WC + 2 * pcol;
+          if (h == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+              const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+              ptab[slot0 - WS + (k & 1) + (k >> 1) * WC] =
+                  ok ? (unsigned)(((long)n * a.x_bs + ((long)yy * W + xx) * 16) * 2) : 0x80000000u;
+            }
+          }
+          in = true;
+        }
+      }
+      sbase[t] = slot0 * 16 + h * (WPL * 16);
       inmask |= (in ? 1u : 0u) << t;
     }
   }
   unsigned aaddr = (unsigned)(r * ROWB + ((h ^ ((r >> 3) & 1)) << 4));
+  if (PR) {
+    // the table is complete: the lanes that own patch slots take their DMA source from it (chunk 0's window is already in
+    // flight with zeros in those slots: wait for it, then fetch the patch slots of chunk 0; later chunks carry them along)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool any = *pcnt != 0u;
+#pragma unroll
+    for (int t = 0; t < WROUNDS; ++t) {
+      const int pi = t * NT + tid;
+      const int pp = pi >= WPL ? 1 : 0, slot = pi - pp * WPL;
+      if (slot >= WS && slot < WS + PR * WC) {
+        const unsigned src = ptab[slot - WS];
+        woff[t] = src == 0x80000000u ? src : src + pp * 16;
+      }
+    }
+    if (any) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int t = 0; t < WROUNDS; ++t) {
+        const int lo = t * NT, hi = lo + NT, pw = PR * WC;       // rounds that hold patch slots of either plane (uniform)
+        if ((lo < WS + pw && hi > WS) || (lo < WPL + WS + pw && hi > WPL + WS))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem + wave * 1024 + t * NT * 16), 16, woff[t], 0, 0, 0);
+      }
+#endif
+    }
+  }
 
   // the accumulators start at the bias (C/D row = (q & 3) + 8 (q >> 2) + 4 h): no dependent bias loads in the epilogue
   f32x16 acc[NA];
@@ -351,19 +426,30 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   }
 }
 
-template <int NA>
+template <int NA, int R, int PR>
 static int db_launch(DbArgs& a, hipStream_t st) {
-  constexpr int NT = 256, WIMG = 9 * NA * 32 * 32, WS_MAX = (4 + 2 * DB_R + 1) * (32 + 2 * DB_R + 1);
-  constexpr int LDS = ((WS_MAX * 2 + NT - 1) / NT + (WIMG + NT * 16 - 1) / (NT * 16)) * NT * 16;
-  static_assert(LDS <= 64 * 1024, "two or three work-groups per CU");
+  using G = DbGeom<R, PR>;
+  constexpr int NT = 256, WIMG = 9 * NA * 32 * 32;
+  constexpr int LDS = G::WIN_BYTES + (WIMG + NT * 16 - 1) / (NT * 16) * NT * 16 + G::AUX_BYTES;
+  static_assert(2 * LDS <= 160 * 1024, "two work-groups per CU");
+  auto kern = dcn_bf16_kernel<NA, R, PR>;
+  if (LDS > 64 * 1024) {
+    static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
+    bool& done = attr_by_dev[sgta_device_slot()];
+    if (!done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return SGTA_EBADARG;
+      done = true;
+    }
+  }
   const int TW = 1 << a.log_tw, TR = 128 >> a.log_tw;
   a.mH = (unsigned)((0x100000000ULL + a.H - 1) / a.H);
-  for (int l = 3; l <= 5; ++l) a.mWC[l - 3] = (unsigned)((0x100000000ULL + (1 << l) + 2 * DB_R) / ((1 << l) + 2 * DB_R + 1));
+  for (int l = 3; l <= 5; ++l) a.mWC[l - 3] = (unsigned)((0x100000000ULL + (1 << l) + 2 * R) / ((1 << l) + 2 * R + 1));
   if ((long)a.N * a.H >= 65536 || a.H < 2) return SGTA_EBADARG;          // umulhi division range
   a.n_rt = cdiv((long)a.N * a.H, TR);
   a.n_xt = cdiv(a.W, TW);
   const int grid = cdiv(a.n_rt * a.n_xt, 8) * 8 * a.n_ct;
-  hipLaunchKernelGGL((dcn_bf16_kernel<NA>), dim3(grid), dim3(NT), LDS, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
@@ -371,13 +457,14 @@ static int db_launch(DbArgs& a, hipStream_t st) {
 // x bf16 blocked [N][Cb][H][W][16] (x_bs elements per image); om f32 NHWC [N,H,W,ldo]: channels 0..17 = (dy, dx) per tap, 18..26 = mask logits (the raw
 // conv_offset_mask output); wt: [n_ct][Cin/16][9][32*na][16] bf16 rows XOR-swizzled in 16-byte pieces (the 3x3 layout of
 // sgta_conv_bf16, ops_bf16.py); bias f32 [n_ct*32*na] (BN folded); y bf16 blocked (y_bs elements per image); act 1 = ReLU.
-// Cin % 16 == 0, Cout % 8 == 0, log_tw in 3..5.
+// Cin % 16 == 0, Cout % 8 == 0.  margin: 6 (window of +-6 pixels round the tile, log_tw in 3..5) or 10 (+-10 pixels and patch
+// slots for the samples beyond, log_tw in 3..4): speed only, every margin gives the same result.
 extern "C" int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
                                    const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
-                                   int na, int log_tw, int act, hipStream_t st) {
+                                   int na, int log_tw, int margin, int act, hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
   if (Cin % 16 || Cout % 8 || x_bs % 16 || y_bs % 16 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 28 || ldo % 4 || ((uintptr_t)om & 15) || log_tw < 3 ||
-      log_tw > 5)
+      log_tw > 5 || (margin != 6 && margin != 10) || (margin == 10 && log_tw > 4))
     return SGTA_EBADARG;
   if (wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if ((long)N * x_bs * 2 > 0x7fffffffL) return SGTA_EBADARG;             // 31-bit byte offsets in the gather
@@ -386,7 +473,7 @@ extern "C" int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, in
   a.x_bytes = ((long)(N - 1) * x_bs + (long)(Cin / 16) * H * W * 16) * 2; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
   a.bias = bias; a.y = reinterpret_cast<__bf16*>(y); a.y_bs = y_bs; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.ngroups = Cin / 16; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act;
-  if (na == 2) return db_launch<2>(a, st);
-  if (na == 4) return db_launch<4>(a, st);
+  if (na == 2) return margin == 6 ? db_launch<2, 6, 0>(a, st) : db_launch<2, 10, 4>(a, st);
+  if (na == 4) return margin == 6 ? db_launch<4, 6, 0>(a, st) : db_launch<4, 10, 4>(a, st);
   return SGTA_EBADARG;
 }

@@ -10,6 +10,9 @@ from . import _lib
 from .ops import ACT_NONE, ACT_RELU, fold_bn, _round_up, _stream  # noqa: F401
 
 OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+DCN_WIDE_MAX_HW = 60 * 80   # maps up to this size use the +-10-pixel window with patch slots (levels 3..5 at 480x640)
+DCN_MARGIN = None           # tests / tools: force the DCN window margin (6 or 10)
+DEBUG_OM_SCALE = None       # tools: multiply the DCN sampling offsets (never set in the product)
 FORCE_NPF = None            # tools / tests: force the conv tile size (1: 256 positions, 2: 512)
 BF16 = torch.bfloat16
 
@@ -257,10 +260,10 @@ class PackedDCNBF16:
         self.bias = bb.float().contiguous()
         self.w_ref = w.clamp(-65504.0, 65504.0).to(torch.float16)
 
-    def tile_log_tw(self, N, H, W):
+    def tile_log_tw(self, N, H, W, margin=6):
         tp = 128                                   # 4 waves x 32 pixels (dcn_bf16.hip); window of <= 765 slots: TW <= 32
         best = None
-        for ltw in (5, 4, 3):
+        for ltw in ((5, 4, 3) if margin == 6 else (4, 3)):
             tw = 1 << ltw
             tr = tp // tw
             work = (-(-W // tw) * tw) * (-(-(N * H) // tr) * tr)
@@ -277,14 +280,18 @@ def dcn_v2(x, om, pc, out, act=ACT_RELU):
     assert x.base.dtype == BF16 and om.base.dtype == torch.float32 and out.base.dtype == BF16
     assert x.C == pc.Cin and out.C == pc.Cout and om.C >= 27 and x.blocked and out.blocked and not om.blocked
     assert (om.N, om.H, om.W) == (x.N, x.H, x.W) == (out.N, out.H, out.W)
+    if DEBUG_OM_SCALE is not None:                 # tools only: scale the sampling offsets (how much of the time is the far-sample path?)
+        om.base[..., :18] *= DEBUG_OM_SCALE
     meta = None
     if _lib.PROFILE is not None:
         M = x.N * x.H * x.W
         meta = {"kernel": "dcn_bf16_kernel<%d>" % pc.na, "flops": pc.flops(M), "exec_flops": pc.flops(M),
                 "bytes": 2.0 * M * (pc.Cin + pc.Cout) + 4.0 * 27 * M + 2.0 * pc.Cout * pc.Cin * 9}
+    # deep levels (small maps) sample far from the output pixel: wide window + patch slots (dcn_bf16.hip); speed only
+    margin = DCN_MARGIN if DCN_MARGIN is not None else (10 if x.H * x.W <= DCN_WIDE_MAX_HW else 6)
     _lib.call("sgta_dcnv2_fwd_bf16", x.ptr, x.bs, om.ptr, om.ld, pc.wt.data_ptr(), pc.wt.numel() * 2,
               pc.bias.data_ptr(), out.ptr, out.bs, x.N, x.H, x.W, pc.Cin, pc.Cout, pc.na,
-              pc.tile_log_tw(x.N, x.H, x.W), act, _stream(), meta=meta)
+              pc.tile_log_tw(x.N, x.H, x.W, margin), margin, act, _stream(), meta=meta)
     return out
 
 

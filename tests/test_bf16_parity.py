@@ -135,7 +135,8 @@ def test_conv_bf16_channel_slices_and_fp32_outputs(bops):
 
 @pytest.mark.parametrize("N,cin,cout,H,W,off_scale", [(2, 64, 64, 17, 23, 1.5), (1, 128, 128, 15, 20, 4.0),
                                                       (3, 64, 256, 9, 12, 0.5), (1, 512, 256, 15, 20, 2.0),
-                                                      (2, 256, 64, 30, 40, 8.0)])
+                                                      (2, 256, 64, 30, 40, 8.0), (4, 128, 128, 60, 80, 3.5),
+                                                      (2, 64, 128, 30, 40, 5.0)])
 def test_dcn_bf16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
     """sgta_dcnv2_fwd_bf16 against oracle.dcn_v2_im2col + GEMM on the bf16-rounded x / weights with the SAME fp32
     offsets and mask logits (border, far-out-of-image and fractional samples)."""
@@ -150,10 +151,17 @@ def test_dcn_bf16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
     ref = F.relu(ref + b.view(1, -1, 1, 1))
     om32 = torch.zeros(N, H, W, 32, device=DEV)
     om32[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
-    out = blocked(N, cout, H, W, 5.0)
-    bops.dcn_v2(bops.ViewH(nhwc(x)), bops.ViewH(om32), pc, bops.ViewH(out), 1)
-    # the blended sample is rounded to bf16 before the product (the fp32 oracle keeps it in fp32): 2^-9 per sample
-    close(nchw(out), ref, rtol=1e-2, atol_rel=4e-3)
+    # both window margins: +-6 pixels (far samples send the wave through the global-memory path) and +-10 pixels with patch
+    # slots (off_scale 0.5 .. 8: no far samples, a few patched ones, more than the patch blocks hold)
+    for margin in (6, 10):
+        out = blocked(N, cout, H, W, 5.0)
+        bops.DCN_MARGIN = margin
+        try:
+            bops.dcn_v2(bops.ViewH(nhwc(x)), bops.ViewH(om32), pc, bops.ViewH(out), 1)
+        finally:
+            bops.DCN_MARGIN = None
+        # the blended sample is rounded to fp16 before the product (the fp32 oracle keeps it in fp32)
+        close(nchw(out), ref, rtol=1e-2, atol_rel=4e-3)
 
 
 def test_elementwise_bf16(bops):
