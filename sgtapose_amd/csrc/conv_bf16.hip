@@ -18,6 +18,7 @@
 // per chunk.  LDS rows are KC*2 bytes; 16-byte pieces are XOR-swizzled with the row index (on the DMA source side for
 // the window, at pack time for the weights) so the ds_read_b128 fragment reads are conflict-free.
 #include "common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -56,8 +57,23 @@ __device__ __forceinline__ float cb_sigmoid(float v) { return 1.0f / (1.0f + __e
 // hidden activations relu(acc + bias) are rounded to bf16 IN REGISTERS -- accumulator registers 8t..8t+7 of a lane are
 // exactly the B operand (k = 8h + j) of a second v_mfma_f32_32x32x16_bf16 whose k order the packed W2 follows -- and
 // multiplied by the (block-diagonal) 1x1 weights of the heads: the hidden tensor never exists in memory.
-template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0>
+//
+// P3 (3x3 stride 1): the chunk loop as a THREE-DEEP pipeline with counted waits.  The two-stage form above waits for
+// vmcnt(0) at every chunk barrier -- the "two barriers per K-step" GEMM structure whose ceiling is ~900 TFLOP/s, which is
+// where these kernels sat (the DMA instructions of chunk k + 1 are issued during chunk k; the last of them land a
+// memory latency after the chunk's MFMAs are done).  Here a chunk is three sub-steps (one tap row = 3 taps = 24-48 MFMAs
+// per wave); the weight image is staged per tap row in a ring of three slots, two sub-steps ahead, the window per chunk in
+// a ring of two, a whole chunk ahead; every sub-step waits only until the loads issued AFTER the data it needs are the
+// only ones outstanding (s_waitcnt vmcnt(N), N = the rounds of one weight image [+ one window]): a load always has at
+// least one full sub-step of matrix work to land in, and nothing in the loop drains the memory pipeline.
+template <int N>
+__device__ __forceinline__ void cb_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
+  static_assert(!P3 || (KS == 3 && S == 1 && KC == 16), "the three-deep pipeline is built for 3x3 stride 1");
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int TC = NA * 32, TAPS = G::TAPS, KSTEPS = G::KSTEPS, P = G::P, ROWB = G::ROWB, LOG_R = G::LOG_R;
   constexpr int PAD = KS / 2;
@@ -180,6 +196,102 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   const int n_it = FUSE ? a.n_ct * a.nchunks : a.nchunks;
   const int wi0 = FUSE ? 0 : ct * a.nchunks;
   int kc = 0, ctl = 0;
+  auto heads_tile = [&]() {
+    // ---- channel tile ctl is complete: hidden = relu(acc + bias) -> bf16 -> second product, accumulators cleared ------
+    const bf16x8* w2 = reinterpret_cast<const bf16x8*>(a.w2) + (long)ctl * NA * 2 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 a2 = w2[(i * 2 + t) * 64];
+        const float* bp = a.bias + ctl * TC + i * 32 + 16 * t + 4 * h;          // rows (j & 3) + 8 (2t + (j >> 2)) + 4h
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 8);
+#pragma unroll
+        for (int f = 0; f < NPF; ++f) {
+          typedef float f32x8 __attribute__((ext_vector_type(8)));
+          f32x8 hv;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) hv[j] = fmaxf(acc[i][f][8 * t + j] + (j < 4 ? b0[j & 3] : b1[j & 3]), 0.0f);
+          acc2[FUSE ? f : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_convertvector(hv, bf16x8), acc2[FUSE ? f : 0], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+      for (int f = 0; f < NPF; ++f)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
+    ++ctl;
+  };
+  if constexpr (P3) {
+    constexpr int WSUBB = 3 * TC * ROWB;                  // bytes of one tap row of the weight image
+    constexpr int AW = (WSUBB + 8191) / 8192, WSUB = AW * 8192, WRN = G::WROUNDS;
+    unsigned char* const win0 = smem;                      // two window slots, then three weight slots
+    unsigned char* const wts0 = smem + 2 * G::WIN_BYTES;
+    unsigned aoff3[AW];
+#pragma unroll
+    for (int t = 0; t < AW; ++t) {
+      const int e = (t * 512 + tid) * 16;
+      aoff3[t] = e < WSUBB ? (unsigned)e : 0x80000000u;
+    }
+    auto dma_win = [&](int kcn, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int j = 0; j < WRN; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(win0 + slot * G::WIN_BYTES + wave * 1024 + j * 8192), 16, woff[j],
+                                                 kcn * a.H * a.W * 32, 0, 0);
+#endif
+    };
+    auto dma_wts = [&](int row, int slot) {               // row = global tap-row index: (weight image index) * 3 + tap row
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int t = 0; t < AW; ++t)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wts0 + slot * WSUB + wave * 1024 + t * 8192), 16, aoff3[t],
+                                                 row * WSUBB, 0, 0);
+#endif
+    };
+    const int total = 3 * n_it;
+    dma_win(0, 0);
+    dma_wts(3 * wi0, 0);
+    dma_wts(3 * wi0 + 1, 1);
+    for (int it = 0; it < n_it; ++it) {
+      const bool more_chunk = it + 1 < n_it;
+      const int nkc = kc + 1 < a.nchunks ? kc + 1 : 0;
+      const unsigned char* Ws = win0 + (it & 1) * G::WIN_BYTES;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int s_ = 3 * it + j;
+        // everything issued BEFORE the data of this sub-step has landed once only the later loads are outstanding:
+        // the weight image of sub-step s + 1 (issued one sub-step ago) and, behind j == 0, the next chunk's window
+        if (s_ + 1 >= total) cb_wait_vm<0>();
+        else if (j == 1 && more_chunk) cb_wait_vm<AW + WRN>();
+        else cb_wait_vm<AW>();
+        __builtin_amdgcn_s_barrier();
+        if (j == 0 && more_chunk) dma_win(nkc, (it + 1) & 1);
+        if (s_ + 2 < total) dma_wts(3 * wi0 + s_ + 2, (j + 2) % 3);
+        const unsigned char* As = wts0 + j * WSUB;
+        bf16x8 afr[2][NA], bfr[2][NPF];
+        auto frags = [&](int tl, bf16x8 (&af)[NA], bf16x8 (&bf)[NPF]) {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + (tl * TC + i * 32) * ROWB + aaddr[0]);
+#pragma unroll
+          for (int f = 0; f < NPF; ++f) bf[f] = *reinterpret_cast<const bf16x8*>(Ws + baddr[3 * j + tl][f]);
+        };
+        frags(0, afr[0], bfr[0]);
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl) {
+          if (tl + 1 < 3) frags(tl + 1, afr[(tl + 1) & 1], bfr[(tl + 1) & 1]);
+#pragma unroll
+          for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int f = 0; f < NPF; ++f)
+              acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tl & 1][i], bfr[tl & 1][f], acc[i][f], 0, 0, 0);
+        }
+      }
+      if (FUSE && nkc == 0) heads_tile();
+      kc = nkc;
+    }
+  } else {
   stage(0, wi0, 0);
   for (int it = 0; it < n_it; ++it) {
     const int st = it & 1;
@@ -219,34 +331,9 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
           if (k * DPK + d < NDMA) dma_one(k * DPK + d, nkc, wi0 + it + 1, st ^ 1);
       }
     }
-    if (FUSE && nkc == 0) {
-      // ---- channel tile ctl is complete: hidden = relu(acc + bias) -> bf16 -> second product, accumulators cleared ------
-      const bf16x8* w2 = reinterpret_cast<const bf16x8*>(a.w2) + (long)ctl * NA * 2 * 64 + lane;
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const bf16x8 a2 = w2[(i * 2 + t) * 64];
-          const float* bp = a.bias + ctl * TC + i * 32 + 16 * t + 4 * h;          // rows (j & 3) + 8 (2t + (j >> 2)) + 4h
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 8);
-#pragma unroll
-          for (int f = 0; f < NPF; ++f) {
-            typedef float f32x8 __attribute__((ext_vector_type(8)));
-            f32x8 hv;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = fmaxf(acc[i][f][8 * t + j] + (j < 4 ? b0[j & 3] : b1[j & 3]), 0.0f);
-            acc2[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_convertvector(hv, bf16x8), acc2[f], 0, 0, 0);
-          }
-        }
-#pragma unroll
-      for (int i = 0; i < NA; ++i)
-#pragma unroll
-        for (int f = 0; f < NPF; ++f)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) acc[i][f][q] = 0.0f;
-      ++ctl;
-    }
+    if (FUSE && nkc == 0) heads_tile();
     kc = nkc;
+  }
   }
 
   if (FUSE) {
@@ -339,13 +426,14 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   }
 }
 
-template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0>
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false>
 static int cb_launch(CbArgs& a, hipStream_t st) {
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int WIMG = KS * KS * NA * 32 * KC * 2;
-  constexpr int LDS = 2 * (G::WIN_BYTES + ((WIMG + 8191) / 8192) * 8192);
+  constexpr int LDS = P3 ? 2 * G::WIN_BYTES + 3 * ((3 * NA * 32 * KC * 2 + 8191) / 8192) * 8192
+                         : 2 * (G::WIN_BYTES + ((WIMG + 8191) / 8192) * 8192);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE>;
+  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE, P3>;
   static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
   bool& done = attr_by_dev[sgta_device_slot()];
   if (!done) {
@@ -388,14 +476,15 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
   const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
   a.n_rt = cdiv((long)N * (a.Ho + 1), TR);
   a.n_xt = cdiv(a.Wo, TW);
+  static const bool p3 = !(getenv("SGTA_CONV_P3") && atoi(getenv("SGTA_CONV_P3")) == 0);   // tools: 0 = the two-stage loop
   if (ks == 3 && stride == 1 && kc == 16 && npf == 2) {
-    if (na == 1) return cb_launch<3, 1, 16, 2, 1>(a, st);
-    if (na == 2) return cb_launch<3, 1, 16, 2, 2>(a, st);
-    if (na == 4) return cb_launch<3, 1, 16, 2, 4>(a, st);
+    if (na == 1) return p3 ? cb_launch<3, 1, 16, 2, 1, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 1>(a, st);
+    if (na == 2) return p3 ? cb_launch<3, 1, 16, 2, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 2>(a, st);
+    if (na == 4) return p3 ? cb_launch<3, 1, 16, 2, 4, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 4>(a, st);
   } else if (ks == 3 && stride == 1 && kc == 16 && npf == 1) {       // half-size tiles: small maps (work-group count / tail)
-    if (na == 1) return cb_launch<3, 1, 16, 1, 1>(a, st);
-    if (na == 2) return cb_launch<3, 1, 16, 1, 2>(a, st);
-    if (na == 4) return cb_launch<3, 1, 16, 1, 4>(a, st);
+    if (na == 1) return p3 ? cb_launch<3, 1, 16, 1, 1, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 1>(a, st);
+    if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 2>(a, st);
+    if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 4>(a, st);
   } else if (ks == 3 && stride == 2 && kc == 16 && npf == 1) {
     if (na == 1) return cb_launch<3, 2, 16, 1, 1>(a, st);
     if (na == 2) return cb_launch<3, 2, 16, 1, 2>(a, st);
@@ -435,6 +524,8 @@ extern "C" int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const voi
   const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
   a.n_rt = cdiv((long)N * (H + 1), TR);
   a.n_xt = cdiv(W, TW);
+  // (the two-stage loop: with six channel tiles per work-group and no output tensor its waits are already hidden, and the
+  // three-deep form's extra barriers cost it 9 % here)
   if (npf == 2) return cb_launch<3, 1, 16, 2, 4, 1>(a, st);
   if (npf == 1) return cb_launch<3, 1, 16, 1, 4, 1>(a, st);
   return SGTA_EBADARG;

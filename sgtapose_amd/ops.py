@@ -350,6 +350,7 @@ def conv2d(x, pc, out, act=ACT_NONE, res=None, res_mode=0, tile=0):
     return out
 
 
+DEBUG_OM_SCALE = None          # tools: multiply the DCN sampling offsets (never set in the product)
 _WINO_EPILOGUES = {(ACT_NONE, 0), (ACT_RELU, 0), (ACT_RELU, 1), (ACT_RELU, 2), (ACT_SIGMOID, 0)}
 _SPLITK_WS = {}
 
@@ -463,6 +464,8 @@ def dcn_v2(x, om, pc, out, act=ACT_NONE, tile=0):
     """Fused modulated deformable conv: ``om`` is the raw 27-channel offset/mask conv output."""
     x, om, out = as_view(x), as_view(om), as_view(out)
     assert om.C == 27 and x.C == pc.Cin and out.C == pc.Cout
+    if DEBUG_OM_SCALE is not None:                 # tools only: scale the sampling offsets (cost of the far-sample path)
+        om.tensor()[:, :18] *= DEBUG_OM_SCALE
     if USE_DCN_LDS_KERNEL and pc.wt_dcn8 is not None and tile == 0:
         code, _ = pc.dcn_tile(x.H, x.W, x.B)
         meta = None

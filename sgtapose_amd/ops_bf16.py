@@ -10,6 +10,7 @@ from . import _lib
 from .ops import ACT_NONE, ACT_RELU, fold_bn, _round_up, _stream  # noqa: F401
 
 OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+HEADS_NPF = 2               # 512-position tiles in the fused head kernel
 DCN_WIDE_MAX_HW = 60 * 80   # maps up to this size use the +-10-pixel window with patch slots (levels 3..5 at 480x640)
 DCN_MARGIN = None           # tests / tools: force the DCN window margin (6 or 10)
 DEBUG_OM_SCALE = None       # tools: multiply the DCN sampling offsets (never set in the product)
@@ -117,6 +118,9 @@ class PackedConvBF16:
         if FORCE_NPF is not None:
             return 1 if self.stride == 2 else FORCE_NPF
         if self.ks == 3 and self.stride == 2:
+            return 1
+        if self.ks == 3 and self.na == 4:
+            # three-deep pipeline (conv_bf16.hip P3): 256-position tiles keep the rings at 80 KB = two work-groups per CU
             return 1
         n_ct = -(-self.Cout // self.TC)
 
@@ -226,7 +230,7 @@ def heads_fused(x, pk, outs, nsig=0):
         fl = pk.pc1.flops(M) + 2.0 * M * pk.Chid * sum(pk.rows)
         meta = {"kernel": "conv_bf16_kernel<3,1,4,heads>", "flops": fl, "exec_flops": pk.pc1.flops(M) + 2.0 * M * pk.Chid * 32,
                 "bytes": 2.0 * pk.pc1.Cin * M + 4.0 * sum(pk.rows) * M + 2.0 * pk.Chid * pk.pc1.Cin * 9}
-    npf = 2 if FORCE_NPF is None else FORCE_NPF
+    npf = HEADS_NPF if FORCE_NPF is None else FORCE_NPF
     ptrs = [o.data_ptr() for o in outs] + [None] * (4 - len(outs))
     rows = list(pk.rows) + [0] * (4 - len(outs))
     _lib.call("sgta_heads_bf16", x.ptr, x.nbytes, x.bs, pk.pc1.wt.data_ptr(), pk.pc1.wt.numel() * 2, pk.pc1.bias.data_ptr(),
