@@ -55,15 +55,14 @@ __global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __
                                                                 long total) {
   constexpr int KS = 2 * F, P = F / 2;
   const int Ho = H * F, Wo = W * F, Cb = C / 16;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int half = (int)(i & 1);
-    long p = i >> 1;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    p /= Ho;
-    const int cb = (int)(p % Cb);
-    const long n = p / Cb;
+  // grid: x = 256-thread blocks over the (pixel, channel half) pairs of one 16-channel block, y = (image, block): 32-bit
+  // index arithmetic only (a flat 64-bit index cost four 64-bit divisions per thread, more than the memory traffic)
+  const int cb = blockIdx.y % Cb;
+  const long n = blockIdx.y / Cb;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < (int)total; i += gridDim.x * 256) {
+    const int half = i & 1;
+    const int p = i >> 1;
+    const int oy = p / Wo, ox = p - oy * Wo;
     const int c = cb * 16 + half * 8;
     const int iy1 = (oy + P) / F, ky1 = oy + P - iy1 * F, iy0 = iy1 - 1, ky0 = ky1 + F;
     const int ix1 = (ox + P) / F, kx1 = ox + P - ix1 * F, ix0 = ix1 - 1, kx0 = kx1 + F;
@@ -98,13 +97,14 @@ extern "C" int sgta_upsample_add_bf16(const void* x, long x_bs, const float* w, 
                                       int N, int C, int H, int W, int f, hipStream_t st) {
   if (!x || !w || !y || N <= 0 || C <= 0 || C % 16 || x_bs % 16 || y_bs % 16 || (skip && s_bs % 16)) return SGTA_EBADARG;
   if (f != 2 && f != 4) return SGTA_EBADARG;
-  const long total = (long)N * H * f * W * f * (C / 8);
-  const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  const long total = (long)H * f * W * f * 2;                  // (pixel, channel half) pairs of one (image, 16-channel block)
+  if (total > 0x7fffffffL || (long)N * (C / 16) > 65535) return SGTA_EBADARG;
+  const dim3 grid((unsigned)((total + 255) / 256), (unsigned)(N * (C / 16)));
   auto xx = reinterpret_cast<const __bf16*>(x);
   auto ss = reinterpret_cast<const __bf16*>(skip);
   auto yy = reinterpret_cast<__bf16*>(y);
-  if (f == 2) hipLaunchKernelGGL(upsample_add_bf16_kernel<2>, dim3(grid), dim3(256), 0, st, xx, x_bs, w, ss, s_bs, yy, y_bs, C, H, W, total);
-  else hipLaunchKernelGGL(upsample_add_bf16_kernel<4>, dim3(grid), dim3(256), 0, st, xx, x_bs, w, ss, s_bs, yy, y_bs, C, H, W, total);
+  if (f == 2) hipLaunchKernelGGL(upsample_add_bf16_kernel<2>, grid, dim3(256), 0, st, xx, x_bs, w, ss, s_bs, yy, y_bs, C, H, W, total);
+  else hipLaunchKernelGGL(upsample_add_bf16_kernel<4>, grid, dim3(256), 0, st, xx, x_bs, w, ss, s_bs, yy, y_bs, C, H, W, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

@@ -22,12 +22,16 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
                                                    const float* __restrict__ pos,
                                                    const float* __restrict__ post,
                                                    float* __restrict__ out, int ldo, int n, int npad,
-                                                   float inv_scale) {
+                                                   float inv_scale, int nb, int qsplit) {
   extern __shared__ float smem[];
   const int ldt = npad + 4;                        // keeps 16-B alignment of the b128 V reads
   float* Kt = smem;                                // [D][ldt]
   float* Vt = smem + D * ldt;                      // [D][ldt]
-  const int b = blockIdx.z, h = blockIdx.y;
+  // 1-D grid, SAMPLE fastest: the work-groups that read the same bias tiles (same head, same query range, different
+  // samples) are dispatched together -- one per XCD slot in turn, so each XCD's L2 serves B / 8 of them from one fetch (the
+  // level-0 bias is 5.6 MB per head: with the sample on the slowest grid axis every work-group streamed it from the
+  // Infinity Cache, 1.4 GB per launch)
+  const int b = blockIdx.x % nb, h = (blockIdx.x / nb) / qsplit, qblk = (blockIdx.x / nb) % qsplit;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
 
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
   const float* posh = pos ? pos + (long)h * n * n : nullptr;
   const int vrow = (li < D ? li : D - 1) * ldt;    // MFMA rows >= D are never read back
 
-  for (int it = blockIdx.x * 4 + wave; it < ntile; it += gridDim.x * 4) {
+  for (int it = qblk * 4 + wave; it < ntile; it += qsplit * 4) {
     const int i = it * 16 + li;
     const int ic = i < n ? i : n - 1;
     // Q fragment: B[k = g][col = li] = Q[i][h*D + 4c + g]
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
 
     float m = -INFINITY, lsum = 0.0f;
     f32x4 o = {0, 0, 0, 0};
-    float bias[4], bias_nx[4];
+    float bias[4];
     auto load_bias = [&](int jt, float* dst) {
       if (ptile) {
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(ptile + (long)jt * 256);
@@ -79,9 +83,19 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
         dst[r] = (j < n) ? (prow ? prow[j] : 0.0f) : -INFINITY;
       }
     };
-    load_bias(0, bias);
-    for (int jt = 0; jt < ntile; ++jt) {
-      if (jt + 1 < ntile) load_bias(jt + 1, bias_nx);
+    // PF bias tiles in flight per wave (see mhca4_kernel: a one-tile prefetch leaves the loop waiting on L2 / Infinity Cache)
+    constexpr int PF = 8;
+    float bq[PF][4];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_bias(u < ntile ? u : ntile - 1, bq[u]);
+    for (int jt0 = 0; jt0 < ntile; jt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+      const int jt = jt0 + u;
+      if (jt >= ntile) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias[r] = bq[u][r];
+      load_bias(jt + PF < ntile ? jt + PF : ntile - 1, bq[u]);
       f32x4 s = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < D / 4; ++c) {
@@ -106,8 +120,7 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
       const f32x4 va = *reinterpret_cast<const f32x4*>(&Vt[vrow + jt * 16 + 4 * g]);  // V[j=4g+r][dd=li]
 #pragma unroll
       for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(va[r], p[r], o, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bias[r] = bias_nx[r];
+      }
     }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
@@ -129,13 +142,17 @@ __global__ __launch_bounds__(256) void mhca_kernel(const float* __restrict__ q, 
 __global__ __launch_bounds__(256) void mhca4_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                     int ldk, const float* __restrict__ v, int ldv,
                                                     const float* __restrict__ post, float* __restrict__ out, int ldo,
-                                                    int n, int npad, float inv_scale) {
+                                                    int n, int npad, float inv_scale, int nb, int qsplit) {
   constexpr int D = 4;
   extern __shared__ float smem[];
   const int ldt = npad + 4;
   float* Kt = smem;                                // [4][ldt]   K transposed (MFMA A operand rows)
   float* Vr = smem + D * ldt;                      // [npad][4]  V rows (one 16-byte broadcast read per key)
-  const int b = blockIdx.z, h = blockIdx.y;
+  // 1-D grid, SAMPLE fastest: the work-groups that read the same bias tiles (same head, same query range, different
+  // samples) are dispatched together -- one per XCD slot in turn, so each XCD's L2 serves B / 8 of them from one fetch (the
+  // level-0 bias is 5.6 MB per head: with the sample on the slowest grid axis every work-group streamed it from the
+  // Infinity Cache, 1.4 GB per launch)
+  const int b = blockIdx.x % nb, h = (blockIdx.x / nb) / qsplit, qblk = (blockIdx.x / nb) % qsplit;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   for (int j = tid; j < npad; j += 256) {
@@ -150,41 +167,51 @@ __global__ __launch_bounds__(256) void mhca4_kernel(const float* __restrict__ q,
   }
   __syncthreads();
   const int ntile = npad / 16;
-  for (int it = blockIdx.x * 4 + wave; it < ntile; it += gridDim.x * 4) {
+  for (int it = qblk * 4 + wave; it < ntile; it += qsplit * 4) {
     const int i = it * 16 + li;
     const int ic = i < n ? i : n - 1;
     const float qf = q[((long)b * n + ic) * ldq + h * D + g];          // B[k = g][col = li]
     const float* ptile = post + (((long)h * ntile + it) * ntile) * 256 + li * 16 + 4 * g;
     float m = -INFINITY, lsum = 0.0f, o[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 bias = *reinterpret_cast<const f32x4*>(ptile);
-    for (int jt = 0; jt < ntile; ++jt) {
-      f32x4 bias_nx = bias;
-      if (jt + 1 < ntile) bias_nx = *reinterpret_cast<const f32x4*>(ptile + (long)(jt + 1) * 256);
-      const float a = Kt[g * ldt + jt * 16 + li];                      // A[row = key li][k = g]
-      f32x4 s = {0, 0, 0, 0};
-      s = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf, s, 0, 0, 0);     // lane (li = query, g): keys jt*16 + 4g + r
-      float e[4];
+    // the bias tiles come from L2 / the Infinity Cache (5.6 MB per head at level 0): a tile of scores is ~200 cycles of work,
+    // a miss a few thousand -- keep PF tiles of bias in flight per wave (a one-tile prefetch left the loop waiting on them)
+    constexpr int PF = 8;
+    f32x4 bq[PF];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], inv_scale, bias[r]);
-      const float mn = fmaxf(fmaxf(m, fmaxf(e[0], e[1])), fmaxf(e[2], e[3]));
-      // all four keys masked and nothing seen yet: keep the state empty (exp(-inf - -inf) would be NaN)
-      const float msafe = mn == -INFINITY ? 0.0f : mn;
-      const float alpha = __expf(m - msafe);
-      m = mn;
-      float p[4];
+    for (int u = 0; u < PF; ++u) bq[u] = *reinterpret_cast<const f32x4*>(ptile + (long)(u < ntile ? u : ntile - 1) * 256);
+    for (int jt0 = 0; jt0 < ntile; jt0 += PF) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = __expf(e[r] - msafe);
-      lsum = fmaf(lsum, alpha, (p[0] + p[1]) + (p[2] + p[3]));
+      for (int u = 0; u < PF; ++u) {
+        const int jt = jt0 + u;
+        if (jt >= ntile) break;
+        const f32x4 bias = bq[u];
+        const int jn = jt + PF < ntile ? jt + PF : ntile - 1;
+        bq[u] = *reinterpret_cast<const f32x4*>(ptile + (long)jn * 256);
+        const float a = Kt[g * ldt + jt * 16 + li];                      // A[row = key li][k = g]
+        f32x4 s = {0, 0, 0, 0};
+        s = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qf, s, 0, 0, 0);     // lane (li = query, g): keys jt*16 + 4g + r
+        float e[4];
 #pragma unroll
-      for (int dd = 0; dd < 4; ++dd) o[dd] *= alpha;
-      const float* vp = Vr + (jt * 16 + 4 * g) * 4;
+        for (int r = 0; r < 4; ++r) e[r] = fmaf(s[r], inv_scale, bias[r]);
+        const float mn = fmaxf(fmaxf(m, fmaxf(e[0], e[1])), fmaxf(e[2], e[3]));
+        // all four keys masked and nothing seen yet: keep the state empty (exp(-inf - -inf) would be NaN)
+        const float msafe = mn == -INFINITY ? 0.0f : mn;
+        const float alpha = __expf(m - msafe);
+        m = mn;
+        float p[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + r * 4);  // V[key 4g + r][0..3], same address across li
+        for (int r = 0; r < 4; ++r) p[r] = __expf(e[r] - msafe);
+        lsum = fmaf(lsum, alpha, (p[0] + p[1]) + (p[2] + p[3]));
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) o[dd] = fmaf(p[r], vv[dd], o[dd]);
+        for (int dd = 0; dd < 4; ++dd) o[dd] *= alpha;
+        const float* vp = Vr + (jt * 16 + 4 * g) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + r * 4);  // V[key 4g + r][0..3], same address across li
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) o[dd] = fmaf(p[r], vv[dd], o[dd]);
+        }
       }
-      bias = bias_nx;
     }
     // merge the four key groups of every query
     float mall = fmaxf(m, __shfl_xor(m, 16));
@@ -216,18 +243,18 @@ static int mhca_launch(const float* q, int ldq, const float* k, int ldk, const f
   const int ntile = npad / 16;
   int qsplit = (ntile + 3) / 4;                    // work-groups along the query axis
   if (qsplit > 8) qsplit = 8;
-  dim3 grid(qsplit, n_heads, B);
+  dim3 grid((unsigned)qsplit * n_heads * B);
   const float inv = 1.0f / sqrtf((float)head_dim);
   size_t lds = (size_t)2 * head_dim * (npad + 4) * sizeof(float);
   if (head_dim == 4 && pos_tiles && !(ldk & 3) && !(ldv & 3) && !(ldo & 3)) {
-    hipLaunchKernelGGL(mhca4_kernel, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_tiles, out, ldo, n, npad, inv);
+    hipLaunchKernelGGL(mhca4_kernel, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_tiles, out, ldo, n, npad, inv, B, qsplit);
     SGTA_LAUNCH_CHECK();
     return SGTA_OK;
   }
   switch (head_dim) {
-    case 4: hipLaunchKernelGGL(mhca_kernel<4>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
-    case 8: hipLaunchKernelGGL(mhca_kernel<8>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
-    case 16: hipLaunchKernelGGL(mhca_kernel<16>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv); break;
+    case 4: hipLaunchKernelGGL(mhca_kernel<4>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv, B, qsplit); break;
+    case 8: hipLaunchKernelGGL(mhca_kernel<8>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv, B, qsplit); break;
+    case 16: hipLaunchKernelGGL(mhca_kernel<16>, grid, dim3(256), lds, st, q, ldq, k, ldk, v, ldv, pos_embed, pos_tiles, out, ldo, n, npad, inv, B, qsplit); break;
     default: return SGTA_EBADARG;
   }
   SGTA_LAUNCH_CHECK();
