@@ -311,6 +311,7 @@ def main():
                          "weights on bf16 MFMA, fp32 accumulate / softmax / LayerNorm / decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--main-priority", type=int, default=None, help="tuning: run the step on a stream of this torch priority")
     ap.add_argument("--early-levels", default=None,
                     help="comma list of pyramid levels whose attention overlaps the backbone on a side stream "
                          "(engine default: 2,3; empty string: none)")
@@ -370,8 +371,15 @@ def main():
     from sgtapose_amd.distributed import gather_keypoints
     state = {}
 
+    main_stream = torch.cuda.Stream(device=dev, priority=args.main_priority) if args.main_priority is not None else None
+
     def local_step():
-        out, dets = det.process_device(*dev_in, static=True)
+        if main_stream is not None:                 # tuning: the step on a stream of the given priority
+            with torch.cuda.stream(main_stream):
+                out, dets = det.process_device(*dev_in, static=True)
+            torch.cuda.current_stream().wait_stream(main_stream)
+        else:
+            out, dets = det.process_device(*dev_in, static=True)
         state["out"], state["dets"], state["kp"] = out, dets, det.keypoints(dets)
 
     def run_step():
