@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __
   // index arithmetic only (a flat 64-bit index cost four 64-bit divisions per thread, more than the memory traffic)
   const int cb = blockIdx.y % Cb;
   const long n = blockIdx.y / Cb;
+  // the block's 16 channels of all KS x KS taps: LDS reads instead of eight 16-byte global loads per thread (the kernel is
+  // bound by vector-memory instruction issue, not by bytes)
+  __shared__ __attribute__((aligned(16))) float wl[KS * KS * 16];
+  for (int e = threadIdx.x; e < KS * KS * 16; e += 256) wl[e] = w[(long)(e >> 4) * C + cb * 16 + (e & 15)];
+  __syncthreads();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < (int)total; i += gridDim.x * 256) {
     const int half = i & 1;
     const int p = i >> 1;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void upsample_add_bf16_kernel(const __bf16* __
       for (int b = 0; b < 2; ++b) {
         if (iys[a] < 0 || iys[a] >= H || ixs[b] < 0 || ixs[b] >= W) continue;
         const f32x8 v = ld8(x + n * x_bs + ((long)cb * H * W + (long)iys[a] * W + ixs[b]) * 16 + half * 8);
-        const float* wp = w + (long)(kys[a] * KS + kxs[b]) * C + c;
+        const float* wp = wl + (kys[a] * KS + kxs[b]) * 16 + half * 8;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -26,10 +26,10 @@ def family(name):
     args = [a.strip() for a in name.split("<")[1].split(">")[0].split(",")] if "<" in name else []
     if "wino" in fam and args:                        # keep the tile shape: same spelling as bench.py's table
         fam += "<%s>" % args[0]
-    elif fam == "conv_bf16_kernel" and len(args) >= 5:    # <KS, S, KC, NPF, NA> -> bench.py's <KS,S,NA>
-        fam += "<%s,%s,%s>" % (args[0], args[1], args[4])
-    elif fam == "dcn_bf16_kernel" and len(args) >= 2:     # <NPF, NA> -> <NA>
-        fam += "<%s>" % args[1]
+    elif fam == "conv_bf16_kernel" and len(args) >= 5:    # <KS, S, KC, NPF, NA, FUSE, P3> -> bench.py's <KS,S,NA[,heads]>
+        fam += "<%s,%s,%s%s>" % (args[0], args[1], args[4], ",heads" if len(args) > 5 and args[5] == "1" else "")
+    elif fam == "dcn_bf16_kernel" and args:               # <NA, R, PR> -> <NA>
+        fam += "<%s>" % args[0]
     return fam
 
 
@@ -38,7 +38,8 @@ def last_step(by):
     runs and the side streams interleave differently in each, so they are summed per kernel family, never paired."""
     keys = list(by.keys())
     stems = [i for i, k in enumerate(keys) if k[1].startswith("stem_")]
-    per_step = 2 if len(stems) >= 2 and any("c16" in keys[i][1] for i in stems) else 1   # f32: one stem launch per frame
+    # one stem launch per frame (f32 / un-fused bf16: stem_c16_kernel, bf16: stem_l0_bf16_kernel)
+    per_step = 2 if len(stems) >= 2 and any(("c16" in keys[i][1] or "stem_l0" in keys[i][1]) for i in stems) else 1
     start = stems[-per_step]
     return [(k[1], by[k]) for k in keys[start:]]
 
