@@ -47,14 +47,18 @@ extern "C" int sgta_prior_argmax(const float* pre_cls, const float* cur_cls, flo
   return SGTA_OK;
 }
 
-// one work-group per (which, b): window ids of one pyramid level + "winner" flags of the scatter.
-// fid[which][b][t], t = kp*w*w + dxi*w + dyi ; win[b][t] = no later token targets the same pixel.
+// S work-groups per (which, b): window ids of one pyramid level + "winner" flags of the scatter.
+// fid[which][b][t], t = kp*w*w + dxi*w + dyi ; win[b][t] = no later token targets the same pixel.  Every work-group
+// computes all n ids (cheap) and takes every S-th 256-token strip of the O(n^2) winner search: level 0 has n = 1183 tokens, and
+// one work-group per sample left 32 CUs busy for 106 us.
 __global__ __launch_bounds__(256) void window_index_kernel(const float* __restrict__ idx_xy,
                                                            long long* __restrict__ fid,
                                                            unsigned char* __restrict__ win, int B,
-                                                           int K, float scale, int r, int H, int W) {
+                                                           int K, float scale, int r, int H, int W, int S) {
   extern __shared__ int sfid[];
-  const int which = blockIdx.x / B, b = blockIdx.x % B;
+  const int slice = blockIdx.x % S, wb = blockIdx.x / S;
+  const int which = wb / B, b = wb % B;
+  if (which == 0 && slice) return;
   const int ww = 2 * r + 1, n = K * ww * ww;
   const float* src = idx_xy + ((long)which * B + b) * K * 2;
   const float hi = (float)(H - 1);
@@ -69,11 +73,11 @@ __global__ __launch_bounds__(256) void window_index_kernel(const float* __restri
     float f = __fadd_rn(__fmul_rn(y, (float)W), x);
     int id = (int)f;                                              // .type(torch.long): truncation
     sfid[t] = id;
-    fid[((long)which * B + b) * n + t] = id;
+    if (slice == 0) fid[((long)which * B + b) * n + t] = id;
   }
   if (which == 0) return;                                         // winners only for the current frame
   __syncthreads();
-  for (int t = threadIdx.x; t < n; t += 256) {
+  for (int t = slice * 256 + threadIdx.x; t < n; t += S * 256) {
     int me = sfid[t];
     bool w1 = true;
     for (int u = t + 1; u < n; ++u) w1 &= (sfid[u] != me);
@@ -85,7 +89,8 @@ extern "C" int sgta_window_index(const float* idx_xy, long long* fid, unsigned c
                                  float scale, int ks, int H, int W, hipStream_t st) {
   if (!idx_xy || !fid || !win || B <= 0 || K <= 0 || ks < 1 || H <= 0 || W <= 0) return SGTA_EBADARG;
   int r = ks / 2, ww = 2 * r + 1, n = K * ww * ww;
-  hipLaunchKernelGGL(window_index_kernel, dim3(2 * B), dim3(256), n * sizeof(int), st, idx_xy, fid, win, B, K, scale, r, H, W);
+  const int S = n > 512 ? 8 : (n > 256 ? 2 : 1);
+  hipLaunchKernelGGL(window_index_kernel, dim3(2 * B * S), dim3(256), n * sizeof(int), st, idx_xy, fid, win, B, K, scale, r, H, W, S);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
