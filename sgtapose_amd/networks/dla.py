@@ -400,8 +400,24 @@ class DLAPlanAWindowSeq(DLAPlanAWindowThree):
             raise RuntimeError("the HIP path is inference-only: call model.eval()")
         return [self.engine().forward(x, list(pre_imgs), list(pre_hms), repro_hm, list(pre_hm_clss), repro_hm_cls)]
 
+    # 'f32' (default) or 'bf16': engine_seq_bf16.EngineSeqBF16 (same interface; also read from opt.compute_dtype)
+    @property
+    def engine_dtype(self):
+        return getattr(self, "_engine_dtype", getattr(self.opt, "compute_dtype", "f32"))
+
+    @engine_dtype.setter
+    def engine_dtype(self, v):
+        if v not in ("f32", "bf16"):
+            raise ValueError("engine_dtype must be 'f32' or 'bf16'")
+        object.__setattr__(self, "_engine_dtype", v)
+        self._engine = None
+
     def engine(self):
         if self._engine is None:
-            from ..engine_seq import EngineSeq
-            self._engine = EngineSeq(self)
+            if self.engine_dtype == "bf16":
+                from ..engine_seq_bf16 import EngineSeqBF16
+                self._engine = EngineSeqBF16(self)
+            else:
+                from ..engine_seq import EngineSeq
+                self._engine = EngineSeq(self)
         return self._engine

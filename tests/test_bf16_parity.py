@@ -304,6 +304,32 @@ def test_bf16_network_matches_fp32_oracle(B, H, W, seed):
         assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
 
 
+@pytest.mark.parametrize("T,B,H,W", [(4, 2, 128, 160), (3, 1, 96, 224)])
+def test_bf16_temporal_window_matches_fp32_oracle(T, B, H, W):
+    """The T-frame model (BASELINE configs[4]) on the bf16 data path (EngineSeqBF16) against the fp32 oracle: the same stated
+    tolerance as the two-frame model on all four heads."""
+    from sgtapose_amd.engine_seq_bf16 import EngineSeqBF16
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from sgtapose_amd.synthetic import SEQ_ARGS, fill_state_dict_, make_inputs_seq
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    m = create_model("dlapawdT_34", heads, default_head_conv(heads), default_opt(seq_len=T))
+    sd = fill_state_dict_({k: v.clone() for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "bf16"
+    assert isinstance(m.engine(), EngineSeqBF16)
+    inp = make_inputs_seq(B, H, W, T=T, seed=77)
+    mv = lambda v: [u.to(DEV) for u in v] if isinstance(v, list) else v.to(DEV)      # noqa: E731
+    out = m(*[mv(inp[k]) for k in SEQ_ARGS])[-1]
+    ref = oracle.plan_a_window_seq_forward(sd, *[inp[k] for k in SEQ_ARGS])
+    assert sorted(out) == ["hm", "reg", "tracking", "wh"]
+    for k in out:
+        d = (out[k].cpu() - ref[k]).abs()
+        print("bf16 T=%d vs fp32 oracle %-8s max %.4f mean %.5f" % (T, k, float(d.max()), float(d.mean())))
+        assert out[k].shape == ref[k].shape
+        assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
+
+
 def test_bf16_detector_keypoints_on_peaked_weights():
     """network -> sigmoid -> decode in bf16 with the peaked weight set.  That set multiplies the 'hm' logits by 30, so the
     bf16 logit noise (~3e-2) becomes ~1 logit and the random-init peak structure is NOT stable under it: the test
