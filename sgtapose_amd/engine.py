@@ -145,8 +145,18 @@ class Engine:
             n=ca.n, C=ca.inp_dim, hid=ca.hid_dim)
 
     # ------------------------------------------------------------------------------------------
+    buf_tag = ""                  # suffix of workspace names while a slice of the batch runs on its own stream (split_levels)
+    split_levels = ()             # backbone levels run as ``split_parts`` slices of the batch on as many streams
+    split_parts = 2
+
+    def _part_streams(self, n):
+        st = getattr(self, "_pstreams", None)
+        if st is None or len(st) < n:
+            st = self._pstreams = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
+        return st[:n]
+
     def buf(self, name, shape, dtype=torch.float32):
-        key = (name, tuple(shape), dtype)
+        key = (name + self.buf_tag, tuple(shape), dtype)
         t = self.bufs.get(key)
         if t is None:
             t = torch.empty(shape, dtype=dtype, device=self.dev)
@@ -249,10 +259,32 @@ class Engine:
         if after_level:
             after_level(1, lv[1])
         ch = self.model.base.channels
+        main = torch.cuda.current_stream()
+        parts = self.split_parts if (self.use_side_stream and _lib.PROFILE is None and self.split_levels) else 1
+        if parts > 1 and N % parts:
+            parts = 2 if N % 2 == 0 else 1
         for i in range(2, 6):
             out = self.vbuf("l%d" % i, N, ch[i], H >> i, W >> i)
-            self._tree(getattr(self.model.base, "level%d" % i), "level%d" % i, lv[i - 1], out,
-                       bottom=pooled if i == 2 else None)
+            node, name = getattr(self.model.base, "level%d" % i), "level%d" % i
+            bottom = pooled if i == 2 else None
+            if parts > 1 and i in self.split_levels:
+                # slices of the batch side by side on their own streams (engine_bf16.py); joined after every level
+                h = N // parts
+                sl = lambda v, k: None if v is None else View(v.base[k * h:(k + 1) * h], v.c0, v.C)     # noqa: E731
+                streams = self._part_streams(parts - 1)
+                for k, st in enumerate(streams):
+                    st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        self.buf_tag = ".p%d" % (k + 1)
+                        try:
+                            self._tree(node, name, sl(lv[i - 1], k + 1), sl(out, k + 1), bottom=sl(bottom, k + 1))
+                        finally:
+                            self.buf_tag = ""
+                self._tree(node, name, sl(lv[i - 1], 0), sl(out, 0), bottom=sl(bottom, 0))
+                for st in streams:
+                    main.wait_stream(st)
+            else:
+                self._tree(node, name, lv[i - 1], out, bottom=bottom)
             lv.append(out)
             if after_level:
                 after_level(i, out)

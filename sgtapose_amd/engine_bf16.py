@@ -82,6 +82,10 @@ class EngineBF16(Engine):
             P["heads.fused"] = None               # unusual head configuration: 3x3 conv + three 1x1 kernels
         self.P = P
 
+    split_levels = (2, 3, 4, 5)   # backbone levels run as ``split_parts`` slices of the batch on as many streams: a level is a
+    split_parts = 2               # chain of launches with 1.2-round tails and latency-bound prologues; independent slices
+    #                               side by side fill those gaps (measured: -3 % on the step)
+
     def hbuf(self, name, n, h, w, c, dtype=BF16):
         """bf16 maps: blocked [n, c/16, h, w, 16]; fp32 maps (DCN offsets): plain channels-last [n, h, w, c]."""
         if dtype == BF16:
@@ -154,9 +158,32 @@ class EngineBF16(Engine):
         if after_level:
             after_level(1, lv[1])
         ch = self.model.base.channels
+        main = torch.cuda.current_stream()
+        parts = self.split_parts if (self.use_side_stream and _lib.PROFILE is None and self.split_levels) else 1
+        if parts > 1 and N % parts:
+            parts = 2 if N % 2 == 0 else 1
         for i in range(2, 6):
             out = self.hbuf("l%d" % i, N, H >> i, W >> i, ch[i])
-            self._tree(getattr(self.model.base, "level%d" % i), "level%d" % i, lv[i - 1], out)
+            node, name = getattr(self.model.base, "level%d" % i), "level%d" % i
+            if parts > 1 and i in self.split_levels:
+                # the batch in ``parts`` slices, slice 0 on this stream and the others on their own streams (a slice depends only
+                # on its own slice of the previous level); they join after every level: the attention hooks and the next level
+                # see the whole map
+                h = N // parts
+                streams = self._part_streams(parts - 1)
+                for k, st in enumerate(streams):
+                    st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        self.buf_tag = ".p%d" % (k + 1)
+                        try:
+                            self._tree(node, name, lv[i - 1].images((k + 1) * h, (k + 2) * h), out.images((k + 1) * h, (k + 2) * h))
+                        finally:
+                            self.buf_tag = ""
+                self._tree(node, name, lv[i - 1].images(0, h), out.images(0, h))
+                for st in streams:
+                    main.wait_stream(st)
+            else:
+                self._tree(node, name, lv[i - 1], out)
             lv.append(out)
             if after_level:
                 after_level(i, out)

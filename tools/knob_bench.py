@@ -13,7 +13,10 @@ args = sys.argv[1:]
 rest = args[args.index("--") + 1:] if "--" in args else []
 for kv in (args[:args.index("--")] if "--" in args else args):
     k, v = kv.split("=", 1)
-    mod, name = k.rsplit(".", 1)
-    setattr(importlib.import_module("sgtapose_amd." + mod), name, eval(v))
+    parts = k.split(".")                                  # module[.Class].attribute
+    obj = importlib.import_module("sgtapose_amd." + parts[0])
+    for a in parts[1:-1]:
+        obj = getattr(obj, a)
+    setattr(obj, parts[-1], eval(v))
 sys.argv = ["bench.py"] + rest
 runpy.run_path(os.path.join(root, "bench.py"), run_name="__main__")
