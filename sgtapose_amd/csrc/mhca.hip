@@ -241,8 +241,10 @@ static int mhca_launch(const float* q, int ldq, const float* k, int ldk, const f
   if (pos_tiles && ((uintptr_t)pos_tiles & 15)) return SGTA_EBADARG;
   const int npad = (n + 15) / 16 * 16;
   const int ntile = npad / 16;
-  int qsplit = (ntile + 3) / 4;                    // work-groups along the query axis
-  if (qsplit > 8) qsplit = 8;
+  // work-groups along the query axis: one 16-query tile per wave where possible (level 0: 74 tiles -> 19 work-groups per
+  // (sample, head); with at most 8 the waves owned 3 / 2 / 2 / 2 tiles and the work-group ran as long as its slowest wave)
+  int qsplit = (ntile + 3) / 4;
+  if (qsplit > 32) qsplit = 32;
   dim3 grid((unsigned)qsplit * n_heads * B);
   const float inv = 1.0f / sqrtf((float)head_dim);
   size_t lds = (size_t)2 * head_dim * (npad + 4) * sizeof(float);
