@@ -144,11 +144,12 @@ def pmc_traffic(kernel, workload):
             return None, "PMC table %s is for %s, this run is %s" % (os.path.basename(PMC_TABLE), meta, workload), None
         for r in csv.DictReader(open(PMC_TABLE)):
             if r["kernel"] == kernel:
-                n = int(r["launches"])
-                byts = (2.0 * float(r["FETCH_SIZE_MB_raw"]) + float(r["WRITE_SIZE_MB_raw"])) * 1e6 / n
-                return round(byts), ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) / %d launches of one step, %s "
-                                     "(separate --pmc passes of this command; not collected live)"
-                                     % (n, os.path.relpath(PMC_TABLE, REPO))), meta.get("commit")
+                # the family's bytes over ONE step; the caller divides by the launches of its own instrumented pass (the timed
+                # step may run a layer as two half-batch launches on two streams, the instrumented pass runs it as one)
+                byts = (2.0 * float(r["FETCH_SIZE_MB_raw"]) + float(r["WRITE_SIZE_MB_raw"])) * 1e6
+                return byts, ("bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) of the kernel family over one step / launches "
+                              "per step, %s (separate --pmc passes of this command; not collected live)"
+                              % os.path.relpath(PMC_TABLE, REPO)), meta.get("commit")
     except (OSError, KeyError, ValueError):
         pass
     return None, "no PMC table for this kernel / workload under profiles/", None
@@ -455,6 +456,8 @@ def main():
         bound = "hbm" if hbm_frac > mfma_frac else "mfma"
         wl = {"batch": B, "height": H, "width": W, "arch": args.arch, "dtype": args.dtype}
         traffic, tnote, tcommit = pmc_traffic(top, wl)
+        if traffic is not None:
+            traffic = round(traffic / max(1, ta["launches"]))
         result["roofline"] = {
             "kernel": top, "bound": bound,
             "achieved": round(gbs if bound == "hbm" else exe, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak,

@@ -30,6 +30,8 @@ def timeit(fn, reps=20):
 
 
 def dcn():
+    if 'MARGIN' in os.environ:
+        bops.DCN_MARGIN = int(os.environ['MARGIN'])
     g = torch.Generator().manual_seed(0)
     for (N, cin, cout, H, W) in ((32, 64, 64, 120, 160), (32, 128, 64, 60, 80), (32, 256, 64, 30, 40), (32, 128, 128, 60, 80),
                                  (32, 256, 256, 30, 40), (32, 512, 256, 15, 20)):

@@ -63,7 +63,7 @@ def main():
         if a["gui"] < 2e4 or not name.strip():
             continue
         t = a["gui"] / 2.0e9
-        lines.append("%s,%d,%.0f,%.3f,%.1f,%.1f,%.0f" % (
+        lines.append("\"%s\",%d,%.0f,%.3f,%.1f,%.1f,%.0f" % (            # quoted: bf16 kernel families carry commas
             name, a["n"], a["gui"], a["mfma"] / 1024 / a["gui"], a["fetch"] * 1024 / 1e6, a["write"] * 1024 / 1e6,
             (a["fetch"] + a["write"]) * 1024 / 1e9 / t))
     txt = "\n".join(lines)
