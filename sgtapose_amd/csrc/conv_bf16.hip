@@ -73,7 +73,7 @@ __device__ __forceinline__ void cb_wait_vm() {
 
 template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
-  static_assert(!P3 || (KS == 3 && S == 1 && KC == 16), "the three-deep pipeline is built for 3x3 stride 1");
+  static_assert(!P3 || (KS == 3 && KC == 16), "the three-deep pipeline is built for 3x3 convolutions");
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int TC = NA * 32, TAPS = G::TAPS, KSTEPS = G::KSTEPS, P = G::P, ROWB = G::ROWB, LOG_R = G::LOG_R;
   constexpr int PAD = KS / 2;
@@ -443,7 +443,10 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
   }
   const int n_pt = a.n_rt * a.n_xt;
   const int grid = cdiv(n_pt, 8) * 8 * (FUSE ? 1 : a.n_ct);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, a);
+  // a single-chunk layer (level1: Cin = 16) only ever uses stage 0 of the two-stage loop: half the LDS = two work-groups per
+  // CU for a kernel that is one DMA round trip, nine MFMAs and an epilogue per work-group
+  const int lds = (!P3 && !FUSE && a.nchunks == 1) ? LDS / 2 : LDS;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
@@ -486,8 +489,9 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
     if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 2>(a, st);
     if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 4>(a, st);
   } else if (ks == 3 && stride == 2 && kc == 16 && npf == 1) {
-    if (na == 1) return cb_launch<3, 2, 16, 1, 1>(a, st);
-    if (na == 2) return cb_launch<3, 2, 16, 1, 2>(a, st);
+    static const bool p3s2 = getenv("SGTA_CONV_P3S2") && atoi(getenv("SGTA_CONV_P3S2")) == 1;
+    if (na == 1) return p3s2 ? cb_launch<3, 2, 16, 1, 1, 0, true>(a, st) : cb_launch<3, 2, 16, 1, 1>(a, st);
+    if (na == 2) return p3s2 ? cb_launch<3, 2, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 2, 16, 1, 2>(a, st);
   } else if (ks == 1 && stride == 1 && kc == 32 && npf == 2) {
     if (na == 1) return cb_launch<1, 1, 32, 2, 1>(a, st);
     if (na == 2) return cb_launch<1, 1, 32, 2, 2>(a, st);
