@@ -35,6 +35,7 @@ struct CbArgs {
   const float* b2;                               // [16]
   float* out[4];                                 // f32 NCHW per head
   int hs[5];                                     // first output row of head i (hs[n_heads..4] = total)
+  int single;                                    // two-stage loop with ONE LDS stage (see the kernel)
 };
 
 template <int KS, int S, int KC, int NPF>
@@ -292,12 +293,19 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       kc = nkc;
     }
   } else {
+  // a.single: ONE LDS stage (a chunk's DMA is issued when every wave is done with the previous one and waited for at once),
+  // half the LDS -> twice the work-groups per CU: for layers of a few chunks the other work-group's matrix work covers the
+  // wait better than a second stage of the same work-group does
   stage(0, wi0, 0);
   for (int it = 0; it < n_it; ++it) {
-    const int st = it & 1;
+    const int st = a.single ? 0 : (it & 1);
+    if (a.single && it) {
+      __builtin_amdgcn_s_barrier();                // every wave has read chunk it - 1
+      stage(kc, wi0 + it, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const bool more = it + 1 < n_it;               // the next chunk's DMA is issued piece by piece between the MFMA groups below
+    const bool more = !a.single && it + 1 < n_it;  // the next chunk's DMA is issued piece by piece between the MFMA groups below
     const int nkc = kc + 1 < a.nchunks ? kc + 1 : 0;
     const unsigned char* Ws = smem + st * STAGE;
     const unsigned char* As = Ws + G::WIN_BYTES;
@@ -445,7 +453,12 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
   const int grid = cdiv(n_pt, 8) * 8 * (FUSE ? 1 : a.n_ct);
   // a single-chunk layer (level1: Cin = 16) only ever uses stage 0 of the two-stage loop: half the LDS = two work-groups per
   // CU for a kernel that is one DMA round trip, nine MFMAs and an epilogue per work-group
-  const int lds = (!P3 && !FUSE && a.nchunks == 1) ? LDS / 2 : LDS;
+  // stride 2 (40 KB windows: two stages = one work-group per CU): ONE stage is 14 % faster at every depth of the network;
+  // SGTA_CONV_SINGLE1 = chunks up to which the 1x1 convolutions use one stage (tools)
+  static const int single_s2 = getenv("SGTA_CONV_SINGLE") ? atoi(getenv("SGTA_CONV_SINGLE")) : 1 << 30;
+  static const int single_1x1 = getenv("SGTA_CONV_SINGLE1") ? atoi(getenv("SGTA_CONV_SINGLE1")) : 0;
+  a.single = (!P3 && !FUSE && ((KS == 3 && S == 2 && a.nchunks <= single_s2) || (KS == 1 && a.nchunks <= single_1x1))) ? 1 : 0;
+  const int lds = (!P3 && !FUSE && (a.nchunks == 1 || a.single)) ? LDS / 2 : LDS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
@@ -470,7 +483,7 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
   if (out_mode == 2 && (y_bs % 4 || Cout % 4)) return SGTA_EBADARG;
   if (out_mode == 0 && (Cout % 4 || y_bs % 16 || ((uintptr_t)y & 15))) return SGTA_EBADARG;        // 16-byte stores
   if (res && (res_bs % 16 || ((uintptr_t)res & 7))) return SGTA_EBADARG;
-  CbArgs a;
+  CbArgs a{};
   a.x = x; a.x_bytes = x_bytes; a.x_bs = x_bs; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
   a.res = reinterpret_cast<const __bf16*>(res); a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cout = Cout;
