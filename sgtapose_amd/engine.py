@@ -398,6 +398,12 @@ class Engine:
         self._ida(m.ida_up, "ida_up", y, 0, len(y))
         return y[-1]
 
+    def neck_heads(self, cur, hm_act=ACT_NONE, static=False):
+        """DCN neck + head branches on the current-frame maps of the six levels."""
+        feat = self.neck(cur)
+        self.last_feat = feat
+        return self.heads(feat, hm_act, static)
+
     def heads(self, feat, hm_act=ACT_NONE, static=False):
         B, h, w = feat.B, feat.H, feat.W
         hidden = self.vbuf("head_hidden", B, sum(self.head_hidden), h, w)
@@ -466,9 +472,7 @@ class Engine:
             for i in (2, 3, 4, 5):
                 self.temporal_scatter(lv[i], B, tok.get(i) or self.temporal_tokens(lv[i], i, idx, B))
             cur = [self._frame(v, 1, B) for v in lv]
-            feat = self.neck(cur)
-            self.last_feat = feat
-            out = self.heads(feat, hm_act, static)
+            out = self.neck_heads(cur, hm_act, static)
             if dead_on_side:
                 main.wait_stream(side)             # the step is complete only when the side work is
             return out

@@ -270,12 +270,48 @@ class EngineBF16(Engine):
                                   self.hbuf("ida_u", x.N, x.H * f, x.W * f, o), f)
             layers[i] = self._deform("%s.node_%d" % (name, j), u, self.hbuf("%s.n%d" % (name, j), x.N, u.H, u.W, o))
 
-    def heads(self, feat, hm_act=ACT_NONE, static=False):
+    neck_parts = 1            # > 1: neck + heads as that many batch slices on as many streams (measured: see DESIGN.md)
+
+    def neck_heads(self, cur, hm_act=ACT_NONE, static=False):
+        B = cur[0].N
+        pk = self.P.get("heads.fused") if self.fuse_heads else None
+        parts = self.neck_parts if (self.use_side_stream and _lib.PROFILE is None and pk is not None) else 1
+        if parts <= 1 or B % parts:
+            return super().neck_heads(cur, hm_act, static)
+        h, w = cur[2].H, cur[2].W
+        outs = [self.buf("out_" + n, (B, r, h, w)) if static else torch.empty((B, r, h, w), dtype=torch.float32, device=self.dev)
+                for n, r in zip(self.head_names, pk.rows)]
+        main, hb = torch.cuda.current_stream(), B // parts
+        streams = self._part_streams(parts - 1)
+        saved, self.use_side_stream = self.use_side_stream, False       # a slice's neck runs serially on its own stream
+
+        def run(k):
+            feat = self.neck([v.images(k * hb, (k + 1) * hb) for v in cur])
+            self.heads(feat, hm_act, static, outs=[o[k * hb:(k + 1) * hb] for o in outs])
+            return feat
+        try:
+            for k, st in enumerate(streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self.buf_tag = ".n%d" % (k + 1)
+                    try:
+                        run(k + 1)
+                    finally:
+                        self.buf_tag = ""
+            self.last_feat = run(0)
+        finally:
+            self.use_side_stream = saved
+        for st in streams:
+            main.wait_stream(st)
+        return dict(zip(self.head_names, outs))
+
+    def heads(self, feat, hm_act=ACT_NONE, static=False, outs=None):
         B, h, w = feat.N, feat.H, feat.W
         pk = self.P.get("heads.fused") if self.fuse_heads else None
         if pk is not None:
-            outs = [self.buf("out_" + n, (B, r, h, w)) if static else torch.empty((B, r, h, w), dtype=torch.float32, device=self.dev)
-                    for n, r in zip(self.head_names, pk.rows)]
+            if outs is None:
+                outs = [self.buf("out_" + n, (B, r, h, w)) if static else torch.empty((B, r, h, w), dtype=torch.float32, device=self.dev)
+                        for n, r in zip(self.head_names, pk.rows)]
             nsig = pk.rows[0] if (self.head_names[0] == "hm" and hm_act == ops.ACT_SIGMOID) else 0
             bops.heads_fused(feat, pk, outs, nsig)
             return dict(zip(self.head_names, outs))

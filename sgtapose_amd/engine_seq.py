@@ -111,9 +111,7 @@ class EngineSeq(EngineThree):
             else:
                 self.temporal_seq(lv, idxs, B, range(6) if self.compute_dead_levels else (2, 3, 4, 5))
             cur = [View(v.base[n_prev * B:]) for v in lv]
-            feat = self.neck(cur)
-            self.last_feat = feat
-            out = self.heads(feat, hm_act, static)
+            out = self.neck_heads(cur, hm_act, static)
             if side is not None:
                 main.wait_stream(side)
             return out

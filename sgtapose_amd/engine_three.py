@@ -116,9 +116,7 @@ class EngineThree(Engine):
             else:
                 self.temporal_three(lv, idx_pp, idx_p, B, range(6) if self.compute_dead_levels else (2, 3, 4, 5))
             cur = [View(v.base[2 * B:]) for v in lv]
-            feat = self.neck(cur)
-            self.last_feat = feat
-            out = self.heads(feat, hm_act, static)
+            out = self.neck_heads(cur, hm_act, static)
             if side is not None:
                 main.wait_stream(side)             # the step is complete only when the side work is
             return out
