@@ -330,6 +330,29 @@ def test_bf16_temporal_window_matches_fp32_oracle(T, B, H, W):
         assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
 
 
+def test_bf16_step_is_deterministic_across_streams():
+    """The bf16 step runs on several streams (attention beside the backbone, dead levels beside the neck, two batch slices per
+    backbone level, DCN projections beside the nodes): twelve consecutive steps on the same inputs must give bit-identical
+    outputs -- a missing stream dependency shows up here as a flicker."""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _bf16_model()
+    det = BatchedDetector(m)
+    inp = make_inputs(6, 128, 160, seed=5)
+    dev_in = [inp[k].to(DEV) for k in ARGS]
+    first = None
+    for i in range(12):
+        out, dets = det.process_device(*dev_in, static=True)
+        cur = {k: v.clone() for k, v in out.items()}
+        cur["kp"] = dets["kp"].clone()
+        if first is None:
+            first = cur
+        else:
+            for k in first:
+                assert torch.equal(first[k], cur[k]), (i, k)
+    torch.cuda.synchronize()
+
+
 def test_bf16_detector_keypoints_on_peaked_weights():
     """network -> sigmoid -> decode in bf16 with the peaked weight set.  That set multiplies the 'hm' logits by 30, so the
     bf16 logit noise (~3e-2) becomes ~1 logit and the random-init peak structure is NOT stable under it: the test

@@ -1113,3 +1113,23 @@ def test_batched_pnp_and_gauss_newton_match_oracle(ops, model):
     for a, b_ in zip(maps[:4], ref_maps):
         assert torch.equal(a, b_)
     assert float(maps[1].max()) == 1.0
+
+
+def test_fp32_step_is_deterministic_across_streams(model):
+    """The step runs on three streams (attention beside the backbone, dead levels beside the neck, DCN projections beside the
+    nodes): consecutive steps on the same inputs give bit-identical outputs -- a missing dependency would flicker."""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    det = BatchedDetector(model)
+    inp = make_inputs(6, 128, 160, seed=5)
+    dev_in = [inp[k].to(DEV) for k in ARGS]
+    first = None
+    for i in range(10):
+        out, dets = det.process_device(*dev_in, static=True)
+        cur = {k: v.clone() for k, v in out.items()}
+        cur["kp"] = dets["kp"].clone()
+        if first is None:
+            first = cur
+        else:
+            for k in first:
+                assert torch.equal(first[k], cur[k]), (i, k)
