@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from .ops import ACT_NONE, ACT_RELU, fold_bn, _round_up, _stream  # noqa: F401
 
-OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+OUT_BF16_BLOCKED, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
 HEADS_NPF = 2               # 512-position tiles in the fused head kernel
 DCN_WIDE_MAX_HW = 60 * 80   # maps up to this size use the +-10-pixel window with patch slots (levels 3..5 at 480x640)
 DCN_MARGIN = None           # tests / tools: force the DCN window margin (6 or 10)
@@ -151,8 +151,8 @@ class PackedConvBF16:
         return 2.0 * M * self.Cout * self.Cin * self.ks * self.ks
 
 
-def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cout=None):
-    """out = act(conv(x) + bias [+ res]).  x: ViewH (bf16); out: ViewH (bf16 NHWC / f32 NHWC) or a contiguous f32 NCHW
+def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_BLOCKED, nsig=0, cout=None):
+    """out = act(conv(x) + bias [+ res]).  x: ViewH (bf16); out: ViewH (bf16 blocked / f32 NHWC) or a contiguous f32 NCHW
     tensor (out_mode = OUT_F32_NCHW, sigmoid on channels < nsig); res: ViewH bf16 at the output resolution."""
     assert x.base.dtype == BF16 and x.C == pc.Cin
     Ho, Wo = (x.H - 1) // pc.stride + 1, (x.W - 1) // pc.stride + 1
@@ -162,10 +162,10 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_NHWC, nsig=0, cou
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (x.N, cout, Ho, Wo)
         yptr, ldy = out.data_ptr(), 0
     else:
-        assert out.base.dtype == (BF16 if out_mode == OUT_BF16_NHWC else torch.float32)
+        assert out.base.dtype == (BF16 if out_mode == OUT_BF16_BLOCKED else torch.float32)
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cout)
-        yptr, ldy = (out.ptr, out.bs) if out_mode == OUT_BF16_NHWC else (out.ptr, out.ld)
-        assert out.blocked == (out_mode == OUT_BF16_NHWC)
+        yptr, ldy = (out.ptr, out.bs) if out_mode == OUT_BF16_BLOCKED else (out.ptr, out.ld)
+        assert out.blocked == (out_mode == OUT_BF16_BLOCKED)
     rp, ldr = None, 0
     if res is not None:
         assert res.base.dtype == BF16 and res.blocked and (res.N, res.H, res.W, res.C) == (x.N, Ho, Wo, cout)
