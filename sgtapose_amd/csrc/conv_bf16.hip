@@ -1,4 +1,4 @@
-// bf16 data path (BASELINE configs[2]): convolution (+ folded BN bias, residual, activation) on bf16 NHWC feature
+// bf16 data path (BASELINE configs[2]): convolution (+ folded BN bias, residual, activation) on bf16 blocked channels-last feature
 // maps with bf16 weights, fp32 accumulation on v_mfma_f32_32x32x16_bf16.  Replaces the same reference code as
 // sgta_conv2d_f32 (dla.py:41-69, :157-231, :302-312; DCN offset/mask conv; heads base_model.py:121-135).
 //
