@@ -348,8 +348,6 @@ def main():
     seq = args.arch == "dlapawdT_34"
     three = args.arch == "dlapawd3_34" or seq
     if args.dtype == "bf16":
-        if three and not seq:
-            raise SystemExit("--dtype bf16 is built for dlapawdl3new_34 and dlapawdT_34")
         model.engine_dtype = "bf16"
     if three:
         args.no_cpu_baseline = True                 # the CPU baseline / parity leg is the two-frame oracle's

@@ -337,10 +337,26 @@ class DLAPlanAWindowThree(nn.Module):
             raise RuntimeError("the HIP path is inference-only: call model.eval()")
         return [self.engine().forward(x, *args)]
 
+    # 'f32' (default) or 'bf16' (engine_three_bf16.EngineThreeBF16); also read from opt.compute_dtype
+    @property
+    def engine_dtype(self):
+        return getattr(self, "_engine_dtype", getattr(self.opt, "compute_dtype", "f32"))
+
+    @engine_dtype.setter
+    def engine_dtype(self, v):
+        if v not in ("f32", "bf16"):
+            raise ValueError("engine_dtype must be 'f32' or 'bf16'")
+        object.__setattr__(self, "_engine_dtype", v)
+        self._engine = None
+
     def engine(self):
         if self._engine is None:
-            from ..engine_three import EngineThree
-            self._engine = EngineThree(self)
+            if self.engine_dtype == "bf16":
+                from ..engine_three_bf16 import EngineThreeBF16
+                self._engine = EngineThreeBF16(self)
+            else:
+                from ..engine_three import EngineThree
+                self._engine = EngineThree(self)
         return self._engine
 
     def invalidate(self):

@@ -330,6 +330,29 @@ def test_bf16_temporal_window_matches_fp32_oracle(T, B, H, W):
         assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
 
 
+@pytest.mark.parametrize("shared", [False, True])
+def test_bf16_three_frame_model_matches_fp32_oracle(shared):
+    """dlapawd3_34 (the reference's DLA_PlanAWindow_Three, separate and shared cross-attention weights) on the bf16 data path
+    against the fp32 oracle: the stated bf16 tolerance on all four heads."""
+    from sgtapose_amd.engine_three_bf16 import EngineThreeBF16
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from sgtapose_amd.synthetic import THREE_ARGS, fill_state_dict_, make_inputs_three
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    m = create_model("dlapawd3_34", heads, default_head_conv(heads), default_opt(shared_ca=shared))
+    sd = fill_state_dict_({k: v.clone() for k, v in m.state_dict().items()}, 4)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "bf16"
+    assert isinstance(m.engine(), EngineThreeBF16)
+    inp = make_inputs_three(2, 128, 160, seed=21)
+    out = m(*[inp[k].to(DEV) for k in THREE_ARGS])[-1]
+    ref = oracle.plan_a_window_three_forward(sd, *[inp[k] for k in THREE_ARGS], shared_ca=shared)
+    for k in ("hm", "reg", "wh", "tracking"):
+        d = (out[k].cpu() - ref[k]).abs()
+        print("bf16 three-frame (shared=%s) %-8s max %.4f mean %.5f" % (shared, k, float(d.max()), float(d.mean())))
+        assert float(d.max()) <= BF16_LOGIT_TOL and float(d.mean()) <= BF16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
+
+
 def test_bf16_step_is_deterministic_across_streams():
     """The bf16 step runs on several streams (attention beside the backbone, dead levels beside the neck, two batch slices per
     backbone level, DCN projections beside the nodes): twelve consecutive steps on the same inputs must give bit-identical
