@@ -136,7 +136,7 @@ def test_conv_bf16_channel_slices_and_fp32_outputs(bops):
 @pytest.mark.parametrize("N,cin,cout,H,W,off_scale", [(2, 64, 64, 17, 23, 1.5), (1, 128, 128, 15, 20, 4.0),
                                                       (3, 64, 256, 9, 12, 0.5), (1, 512, 256, 15, 20, 2.0),
                                                       (2, 256, 64, 30, 40, 8.0), (4, 128, 128, 60, 80, 3.5),
-                                                      (2, 64, 128, 30, 40, 5.0)])
+                                                      (2, 64, 128, 30, 40, 5.0), (1, 64, 64, 120, 160, 3.0)])
 def test_dcn_bf16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
     """sgta_dcnv2_fwd_bf16 against oracle.dcn_v2_im2col + GEMM on the bf16-rounded x / weights with the SAME fp32
     offsets and mask logits (border, far-out-of-image and fractional samples)."""
