@@ -2,12 +2,10 @@
 v_mfma_f32_32x32x16_bf16, fp32 accumulation; everything that leaves the bf16 domain (DCN offsets / masks, head outputs,
 attention tokens, decode) is fp32.  torch is plumbing only; every function enqueues hand-written HIP kernels.
 """
-import ctypes
-
 import torch
 
 from . import _lib
-from .ops import ACT_NONE, ACT_RELU, fold_bn, _round_up, _stream  # noqa: F401
+from .ops import ACT_NONE, ACT_RELU, fold_bn, _stream
 
 OUT_BF16_BLOCKED, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
 HEADS_NPF = 2               # 512-position tiles in the fused head kernel
