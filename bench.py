@@ -49,9 +49,9 @@ def log(*a):
 # ---------------------------------------------------------------------------------------------------------
 # self-launch: one fresh process per GPU, started BEFORE anything in this process touches the GPU
 # ---------------------------------------------------------------------------------------------------------
-def spawn_ranks(n, need_gpus=True):
-    if need_gpus and torch.cuda.device_count() < n:          # counting devices does not initialise the GPU
-        raise SystemExit("--gpus %d but only %d GPU(s) visible" % (n, torch.cuda.device_count()))
+def spawn_ranks(n, timeout_s=1500.0):
+    """The parent makes no torch.cuda / HIP call at all (not even a device count): a rank whose LOCAL_RANK has no GPU
+    fails in its own torch.cuda.set_device and takes the run down with it."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -63,9 +63,16 @@ def spawn_ranks(n, need_gpus=True):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
+    t_start = time.perf_counter()
     try:
         pending = list(enumerate(procs))
         while pending:
+            if time.perf_counter() - t_start > timeout_s:
+                log("ranks still running after %.0f s: terminating them" % timeout_s)
+                for _, q in pending:
+                    q.terminate()
+                rc = rc or 124
+                break
             for item in list(pending):
                 r, p = item
                 code = p.poll()
@@ -312,7 +319,6 @@ def main():
                          "weights on bf16 MFMA, fp32 accumulate / softmax / LayerNorm / decode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--main-priority", type=int, default=None, help="tuning: run the step on a stream of this torch priority")
     ap.add_argument("--early-levels", default=None,
                     help="comma list of pyramid levels whose attention overlaps the backbone on a side stream "
                          "(engine default: 2,3; empty string: none)")
@@ -325,7 +331,7 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args.gpus, need_gpus=not args.dry_run))     # parent: never touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus))     # parent: never touches the GPU
     if args.dry_run:
         return dry_run(args)
 
@@ -370,15 +376,8 @@ def main():
     from sgtapose_amd.distributed import gather_keypoints
     state = {}
 
-    main_stream = torch.cuda.Stream(device=dev, priority=args.main_priority) if args.main_priority is not None else None
-
     def local_step():
-        if main_stream is not None:                 # tuning: the step on a stream of the given priority
-            with torch.cuda.stream(main_stream):
-                out, dets = det.process_device(*dev_in, static=True)
-            torch.cuda.current_stream().wait_stream(main_stream)
-        else:
-            out, dets = det.process_device(*dev_in, static=True)
+        out, dets = det.process_device(*dev_in, static=True)
         state["out"], state["dets"], state["kp"] = out, dets, det.keypoints(dets)
 
     def run_step():

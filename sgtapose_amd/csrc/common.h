@@ -5,6 +5,7 @@
 
 #define SGTA_OK 0
 #define SGTA_EBADARG (-1)
+#define SGTA_ETOOBIG (-2)   // a size beyond a stated maximum of an entry point that owns its scratch memory
 
 // launch-site error check: returns hipError_t (>0) from the enclosing extern "C" entry point
 #define SGTA_LAUNCH_CHECK()                         \
@@ -18,6 +19,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Tuning switches of the tools/ scripts (kernel-variant A/B runs): read from the environment only in a build with
+// -DSGTA_TOOLS (make TOOLS=1); the product library has no environment switches and always takes ``dflt``.
+#ifdef SGTA_TOOLS
+#include <cstdlib>
+static inline int sgta_tool_env(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#else
+static inline int sgta_tool_env(const char*, int dflt) { return dflt; }
+#endif
 
 // Host-side caches of per-device facts (resident work-groups, function attributes) are indexed by the CURRENT device:
 // one process may drive several GPUs (tests, replicas), and hipFuncSetAttribute is per-device state.

@@ -265,7 +265,7 @@ extern "C" int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* w
   // tile = 10*MT + t : MT in {1,2} = 32 / 64 couts per work-group; t in {0,1,2} = 8x32 / 16x16 / 32x8 output tiles
   const int mt = tile / 10, tw = tile % 10;
   // 16-byte window DMA where rows and planes are 16-byte aligned (SGTA_S2_VEC=0 keeps the 4-byte de-interleaved form)
-  static const bool allow_vec = !(getenv("SGTA_S2_VEC") && atoi(getenv("SGTA_S2_VEC")) == 0);
+  static const bool allow_vec = sgta_tool_env("SGTA_S2_VEC", 1) != 0;
   const bool vec = allow_vec && W % 4 == 0 && x_bs % 4 == 0 && ((uintptr_t)x & 15) == 0;
   if (mt == 2 && Cout_pad % 64 == 0) {
     if (tw == 0) return vec ? go(conv3x3_s2_kernel<2, 32, true>, 64, 32) : go(conv3x3_s2_kernel<2, 32, false>, 64, 32);

@@ -502,7 +502,7 @@ extern "C" int sgta_conv3x3_wino_f32(const float* x, long x_bs, const float* u, 
   a.vec = aligned(4) ? 4 : (aligned(2) ? 2 : 1);
   // two 32-channel groups per work-group (shared window): measured +7 % on the 120x160 maps but -5 % on the 15x20
   // ones (half the items) and neutral at 30x40 -- the maps this kernel serves -- so it is opt-in (SGTA_WINO_NCG=2)
-  static const bool allow_wide = getenv("SGTA_WINO_NCG") && atoi(getenv("SGTA_WINO_NCG")) == 2;
+  static const bool allow_wide = sgta_tool_env("SGTA_WINO_NCG", 1) == 2;
   const bool wide = allow_wide && (Cout_pad % 64 == 0);
   if (act == 1 && res_mode == 0) return wide ? launch_wino<1, 0, 2>(a, tile, wsf, st) : launch_wino<1, 0, 1>(a, tile, wsf, st);
   if (act == 0 && res_mode == 0) return wide ? launch_wino<0, 0, 2>(a, tile, wsf, st) : launch_wino<0, 0, 1>(a, tile, wsf, st);

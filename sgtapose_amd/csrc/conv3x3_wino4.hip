@@ -334,7 +334,7 @@ static int launch_wino4(Wino4Args& a, int tile, hipStream_t st) {
   };
   // tile t in {0,1,2,3} = 2x32 / 4x16 / 8x8 / 16x4 blocks of 4x4 output tiles
   if (NCG == 2 && ACT == 1 && RES == 0 && tile == 0 && a.Cin == 16 && a.Cout_pad == 32) {
-    static const int l0 = getenv("SGTA_L0_FORM") ? atoi(getenv("SGTA_L0_FORM")) : 1;
+    static const int l0 = sgta_tool_env("SGTA_L0_FORM", 1);
     if (l0 == 1 && a.Cout <= 16) {
       // 4-wave work-groups of 16 output channels, two per CU (16x64-pixel blocks keep ring + resident U under 80 KB):
       // no idle channel group, 0.62-0.66 ms against 0.72 for the 8-wave form (SGTA_L0_FORM=0) on level0
@@ -385,7 +385,7 @@ extern "C" int sgta_conv3x3_wino4_f32(const float* x, long x_bs, const float* u,
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Cout_pad = Cout_pad; a.nchunks = Cin / 4;
   // two channel groups per work-group (shared window: +5-10 % measured on every layer shape of the workload)
   // whenever the layer has them; SGTA_WINO4_NCG=1 forces the 4-wave form
-  static const bool allow_wide = !(getenv("SGTA_WINO4_NCG") && atoi(getenv("SGTA_WINO4_NCG")) == 1);
+  static const bool allow_wide = sgta_tool_env("SGTA_WINO4_NCG", 2) != 1;
   const bool wide = allow_wide && (Cout_pad % 32 == 0);
   if (act == 1 && res_mode == 0) return wide ? launch_wino4<1, 0, 2>(a, tile, st) : launch_wino4<1, 0, 1>(a, tile, st);
   if (act == 0 && res_mode == 0) return wide ? launch_wino4<0, 0, 2>(a, tile, st) : launch_wino4<0, 0, 1>(a, tile, st);

@@ -455,8 +455,8 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
   // CU for a kernel that is one DMA round trip, nine MFMAs and an epilogue per work-group
   // stride 2 (40 KB windows: two stages = one work-group per CU): ONE stage is 14 % faster at every depth of the network;
   // SGTA_CONV_SINGLE1 = chunks up to which the 1x1 convolutions use one stage (tools)
-  static const int single_s2 = getenv("SGTA_CONV_SINGLE") ? atoi(getenv("SGTA_CONV_SINGLE")) : 1 << 30;
-  static const int single_1x1 = getenv("SGTA_CONV_SINGLE1") ? atoi(getenv("SGTA_CONV_SINGLE1")) : 0;
+  static const int single_s2 = sgta_tool_env("SGTA_CONV_SINGLE", 1 << 30);
+  static const int single_1x1 = sgta_tool_env("SGTA_CONV_SINGLE1", 0);
   a.single = (!P3 && !FUSE && ((KS == 3 && S == 2 && a.nchunks <= single_s2) || (KS == 1 && a.nchunks <= single_1x1))) ? 1 : 0;
   const int lds = (!P3 && !FUSE && (a.nchunks == 1 || a.single)) ? LDS / 2 : LDS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
@@ -492,7 +492,7 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
   const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
   a.n_rt = cdiv((long)N * (a.Ho + 1), TR);
   a.n_xt = cdiv(a.Wo, TW);
-  static const bool p3 = !(getenv("SGTA_CONV_P3") && atoi(getenv("SGTA_CONV_P3")) == 0);   // tools: 0 = the two-stage loop
+  static const bool p3 = sgta_tool_env("SGTA_CONV_P3", 1) != 0;   // tools: 0 = the two-stage loop
   if (ks == 3 && stride == 1 && kc == 16 && npf == 2) {
     if (na == 1) return p3 ? cb_launch<3, 1, 16, 2, 1, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 1>(a, st);
     if (na == 2) return p3 ? cb_launch<3, 1, 16, 2, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 2>(a, st);
@@ -502,7 +502,7 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
     if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 2>(a, st);
     if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 4>(a, st);
   } else if (ks == 3 && stride == 2 && kc == 16 && npf == 1) {
-    static const bool p3s2 = getenv("SGTA_CONV_P3S2") && atoi(getenv("SGTA_CONV_P3S2")) == 1;
+    static const bool p3s2 = sgta_tool_env("SGTA_CONV_P3S2", 0) == 1;
     if (na == 1) return p3s2 ? cb_launch<3, 2, 16, 1, 1, 0, true>(a, st) : cb_launch<3, 2, 16, 1, 1>(a, st);
     if (na == 2) return p3s2 ? cb_launch<3, 2, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 2, 16, 1, 2>(a, st);
   } else if (ks == 1 && stride == 1 && kc == 32 && npf == 2) {

@@ -283,7 +283,7 @@ static int launch_dcn_patch(DcnArgs& a, int tile, hipStream_t st) {
   // t in {0,1,2} = 4x32 / 8x16 / 16x8 (rows x cols)
   const int mt = tile / 10, tw = tile % 10;
   // 16-byte window DMA where image rows and planes are 16-byte aligned (SGTA_DCN_VEC=0: always the 4-byte form)
-  static const bool allow_vec = !(getenv("SGTA_DCN_VEC") && atoi(getenv("SGTA_DCN_VEC")) == 0);
+  static const bool allow_vec = sgta_tool_env("SGTA_DCN_VEC", 1) != 0;
   const bool vec = allow_vec && a.W % 4 == 0 && a.x_bs % 4 == 0 && ((uintptr_t)a.x & 15) == 0;
   if (mt == 2 && a.Cout_pad % 64 == 0) {
     if (tw == 0) return vec ? go(dcn_patch_kernel<2, 1, 32, R, CK, ACT, true>, 64, 1, 32) : go(dcn_patch_kernel<2, 1, 32, R, CK, ACT, false>, 64, 1, 32);

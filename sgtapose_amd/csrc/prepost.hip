@@ -38,14 +38,23 @@ __global__ __launch_bounds__(128) void render_prior_kernel(const double* __restr
   else atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));   // positive floats order like their bit patterns
 }
 
+// zero fill by a kernel, not hipMemsetAsync: a memset node recorded into a captured graph is not safe to replay
+__global__ __launch_bounds__(256) void zero_f32x4_kernel(float* __restrict__ p, long n) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) *reinterpret_cast<f32x4*>(p + i) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  else
+    for (long j = i; j < n; ++j) p[j] = 0.0f;
+}
+
 extern "C" int sgta_render_priors(const double* kps, const double* trans, const int* raw_wh,
                                   const unsigned char* has_prior, const float* table, float* out, int B, int K,
                                   int Hm, int Wm, int per_class, hipStream_t st) {
   if (!kps || !trans || !raw_wh || !has_prior || !table || !out || B <= 0 || K <= 0 || Hm <= 0 || Wm <= 0)
     return SGTA_EBADARG;
-  const size_t bytes = (size_t)B * (per_class ? K : 1) * Hm * Wm * sizeof(float);
-  hipError_t e = hipMemsetAsync(out, 0, bytes, st);
-  if (e != hipSuccess) return (int)e;
+  const long n = (long)B * (per_class ? K : 1) * Hm * Wm;
+  if (((uintptr_t)out & 15) != 0) return SGTA_EBADARG;                 // 16-byte stores in the fill
+  hipLaunchKernelGGL(zero_f32x4_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, st, out, n);
+  SGTA_LAUNCH_CHECK();
   hipLaunchKernelGGL(render_prior_kernel, dim3(B * K), dim3(128), 0, st, kps, trans, raw_wh, has_prior, table, out,
                      K, Hm, Wm, per_class);
   SGTA_LAUNCH_CHECK();

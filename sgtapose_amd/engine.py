@@ -45,9 +45,6 @@ class CachedStem:
         return self.stem.device
 
 
-SIDE_PRIORITY = 0
-NECK_PRIORITY = 0
-
 
 class Engine:
     def __init__(self, model):
@@ -62,8 +59,6 @@ class Engine:
         self.ks = list(model.kernel_list)
         self.scales = list(model.scale_list)
         self.num_classes = int(model.opt.num_classes)
-        self.side_priority = SIDE_PRIORITY   # torch stream priorities (lower = served first) of the attention / neck side streams
-        self.neck_priority = NECK_PRIORITY
         self.use_side_stream = True          # side stream: early_levels beside the backbone, levels 0/1 beside the neck
         self.early_levels = (2, 3)           # levels whose attention (minus write-back) overlaps the deeper backbone
         self.use_c16 = True                  # 16-cout MFMA kernel for the fused 7x7 stems (False: generic conv)
@@ -484,10 +479,10 @@ class Engine:
 
     def _neck_stream(self):
         if getattr(self, "_side2", None) is None:
-            self._side2 = torch.cuda.Stream(device=self.dev, priority=self.neck_priority)
+            self._side2 = torch.cuda.Stream(device=self.dev)        # every stream at the default priority
         return self._side2
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev, priority=self.side_priority)
+            self._side = torch.cuda.Stream(device=self.dev)
         return self._side
