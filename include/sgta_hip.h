@@ -4,9 +4,13 @@
  * ``ctypes.cdll.LoadLibrary`` + ``extern "C" LM(double*, ..., int)`` (sgtapose/rf_tools/LM.py:10,
  * :256-266); this library follows it: plain C functions, raw device pointers owned by the caller
  * (inputs, outputs AND workspaces are allocated by the caller, e.g. torch), explicit sizes, the HIP
- * stream as the last argument.  No global state, no allocation, no synchronisation inside: every
- * entry point only enqueues kernels on ``stream`` and is safe to capture in a hipGraph and to call
- * from several host threads on distinct streams.
+ * stream as the last argument.  No allocation and no synchronisation inside: every entry point only
+ * enqueues kernels on ``stream`` (device memory is cleared by fill kernels, never by hipMemsetAsync), so a
+ * sequence of calls can be captured in a hipGraph.  The only host-side state is a per-device cache of
+ * one-time kernel attributes (hipFuncSetAttribute for kernels that need more than 64 KB of LDS, the
+ * device's CU count): the first call of a kernel on a device sets them, so run every shape once before
+ * capturing.  Calls from several host threads on distinct streams are safe once those first calls are
+ * done.  The library reads no environment variables.
  *
  * Return value: 0 = ok, < 0 = bad argument (SGTA_EBADARG = -1), > 0 = hipError_t of the launch.
  * All tensors are contiguous float32 NCHW unless a batch stride ``*_bs`` (in ELEMENTS) is given,
@@ -26,6 +30,7 @@ typedef struct ihipStream_t* sgta_stream_t; /* == hipStream_t */
 
 #define SGTA_OK 0
 #define SGTA_EBADARG (-1)
+#define SGTA_ETOOBIG (-2) /* a size beyond the stated maximum of an entry point that owns its scratch memory */
 #define SGTA_ACT_NONE 0
 #define SGTA_ACT_RELU 1
 #define SGTA_ACT_SIGMOID 2
@@ -253,6 +258,18 @@ int sgta_peaks_decode_kp(const float* hm, const float* reg, const float* trackin
                          float* regs, float* trks, int* npeaks, long long* cts, float* cts_wreg,
                          float* regs_rel, float* kp, int B, int K, int H, int W, int three_pass,
                          sgta_stream_t stream);
+
+/* sgta_peaks_decode_kp for callers that cannot allocate device memory.  It has NO counterpart in the reference: it exists for
+ * code under hipGraph capture, tight serving loops and harnesses that forbid hipMalloc.  Same kernels, same outputs; the two
+ * hm-sized workspaces (ws_tmp: per-tile peak candidates, ws_filt: the filtered maps) live in a device array owned by the library
+ * (36 MiB per GPU the library runs on, held until the process ends) instead of caller buffers, and the call allocates nothing.
+ * B*K*H*W must not exceed sgta_peaks_decode_static_max_elems() (4 718 592: 32 x 7 x 120 x 160 fits), else SGTA_ETOOBIG.
+ * All calls on one GPU share that array: calls that overlap in time on one GPU race; nothing in it needs clearing. */
+int sgta_peaks_decode_kp_static(const float* hm, const float* reg, const float* tracking, const double* gauss_w13,
+                                float* scores, long long* xs, long long* ys, float* regs, float* trks, int* npeaks,
+                                long long* cts, float* cts_wreg, float* regs_rel, float* kp, int B, int K, int H, int W,
+                                int three_pass, sgta_stream_t stream);
+long sgta_peaks_decode_static_max_elems(void);
 
 /* SoftArgmaxPavlo.forward (sgtapose/spatial_softmax.py:24-95): out_xy f32 [B,K,2] = (E[col], E[row]). */
 int sgta_softargmax(const float* hm, float* out_xy, int B, int K, int H, int W, float beta,

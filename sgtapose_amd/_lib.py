@@ -43,6 +43,8 @@ SIGNATURES = {
     "sgta_peaks_decode": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "sgta_peaks_decode_full": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_peaks_decode_kp": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_peaks_decode_kp_static": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_peaks_decode_static_max_elems": [],
     "sgta_render_priors": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_post_process": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "sgta_conv_bf16": [_p, _l, _l, _p, _l, _p, _p, _l, _p, _l] + [_i] * 14 + [_p],
@@ -80,7 +82,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError = header / library out of sync: loud
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_long if name.endswith("_max_elems") else ctypes.c_int
     _lib = lib
     return lib
 
@@ -101,6 +103,6 @@ def call(name, *args, meta=None):
     else:
         rc = getattr(load(), name)(*args)
     if rc != 0:
-        kind = "bad argument" if rc < 0 else "hipError_t"
+        kind = ("size beyond the entry point's stated maximum" if rc == -2 else "bad argument") if rc < 0 else "hipError_t"
         raise SgtaHipError("%s failed: %s %d" % (name, kind, rc))
     return rc

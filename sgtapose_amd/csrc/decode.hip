@@ -387,6 +387,44 @@ extern "C" int sgta_peaks_decode_kp(const float* hm, const float* reg, const flo
   return SGTA_OK;
 }
 
+// ---- the decode for callers that cannot allocate device memory (code under hipGraph capture, serving loops, harnesses that
+// forbid hipMalloc): sgta_peaks_decode_kp with its two hm-sized workspaces in a file-scope device array instead of caller
+// buffers.  Every GPU the library runs on holds its own copy of the array (36 MiB) until the process ends.  In host code
+// the array's NAME is only a handle: the device address is taken once per device with hipGetSymbolAddress (that device
+// current) and only that pointer is ever passed to kernels.  Nothing has to start at zero (both halves are fully written
+// before they are read); the array keeps the last call's contents, and two calls that overlap on one GPU race on it.
+#define SGTA_DECODE_STATIC_MAX_ELEMS 4718592L          /* B*K*H*W <= 4.5 Mi: e.g. 32 x 7 x 120 x 160 */
+static __device__ __align__(256) float scratch[2 * SGTA_DECODE_STATIC_MAX_ELEMS];
+
+static float* decode_scratch_ptr(hipError_t* err) {
+  static float* ptr_by_dev[SGTA_MAX_DEVICES] = {};
+  float*& p = ptr_by_dev[sgta_device_slot()];
+  *err = hipSuccess;
+  if (!p) {
+    void* q = nullptr;
+    *err = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));     // the current device's copy of the array
+    if (*err != hipSuccess) return nullptr;
+    p = static_cast<float*>(q);
+  }
+  return p;
+}
+
+extern "C" long sgta_peaks_decode_static_max_elems(void) { return SGTA_DECODE_STATIC_MAX_ELEMS; }
+
+extern "C" int sgta_peaks_decode_kp_static(const float* hm, const float* reg, const float* tracking,
+                                           const double* gauss_w13, float* scores, long long* xs, long long* ys,
+                                           float* regs, float* trks, int* npeaks, long long* cts, float* cts_wreg,
+                                           float* regs_rel, float* kp, int B, int K, int H, int W, int three_pass,
+                                           hipStream_t st) {
+  if (B <= 0 || K <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
+  if ((long)B * K * H * W > SGTA_DECODE_STATIC_MAX_ELEMS) return SGTA_ETOOBIG;
+  hipError_t e;
+  float* ws = decode_scratch_ptr(&e);
+  if (!ws) return e != hipSuccess ? (int)e : SGTA_EBADARG;
+  return sgta_peaks_decode_kp(hm, reg, tracking, gauss_w13, ws, ws + SGTA_DECODE_STATIC_MAX_ELEMS, scores, xs, ys, regs,
+                              trks, npeaks, cts, cts_wreg, regs_rel, kp, B, K, H, W, three_pass, st);
+}
+
 // ---- SoftArgmaxPavlo: AvgPool2d(7,1,3) (zero pad, /49) -> -max -> exp(beta*x) -> /(sum+1e-8) -> E[x],E[y]
 __device__ __forceinline__ float pool7(const float* m, int y, int x, int H, int W) {
   float s = 0.0f;

@@ -659,6 +659,29 @@ def peaks_decode(hm, reg=None, tracking=None, ws=None, three_pass=False, out=Non
     return out
 
 
+def peaks_decode_static(hm, reg, tracking, out, three_pass=False):
+    """``peaks_decode`` for callers that may not allocate: the two workspaces live in a device array owned by the library
+    (sgta_peaks_decode_kp_static), every output is the caller's (``out`` = ``decode_buffers``).  B*K*H*W is limited to
+    ``sgta_peaks_decode_static_max_elems()``; calls that overlap on one GPU race on the shared array."""
+    _req(hm)
+    B, K, H, W = hm.shape
+    if not hm.is_contiguous() or (reg is not None and not reg.is_contiguous()) or \
+            (tracking is not None and not tracking.is_contiguous()):
+        raise _lib.SgtaHipError("peaks_decode_static takes contiguous tensors (it makes no copies)")
+    lim = _lib.load().sgta_peaks_decode_static_max_elems()
+    if B * K * H * W > lim:
+        raise _lib.SgtaHipError("peaks_decode_static: B*K*H*W = %d exceeds the library's static scratch (%d elements); "
+                                "use peaks_decode with caller workspaces" % (B * K * H * W, lim))
+    _lib.call("sgta_peaks_decode_kp_static", hm.data_ptr(), None if reg is None else _req(reg).data_ptr(),
+              None if tracking is None else _req(tracking).data_ptr(), gauss_taps(hm.device).data_ptr(),
+              out["scores"].data_ptr(), out["xs"].data_ptr(), out["ys"].data_ptr(), out["regs"].data_ptr(),
+              out["trks"].data_ptr(), out["npeaks"].data_ptr(), out["cts"].data_ptr(),
+              out["cts_wreg"].data_ptr() if reg is not None else None,
+              out["regs_rel"].data_ptr() if reg is not None else None, out["kp"].data_ptr(), B, K, H, W,
+              int(three_pass), _stream())
+    return out
+
+
 def soft_argmax(hm, beta=25.0, size_mult=1.0):
     _req(hm)
     B, K, H, W = hm.shape

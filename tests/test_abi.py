@@ -21,7 +21,7 @@ def lib():
 
 def header_symbols():
     src = open(os.path.join(REPO, "include", "sgta_hip.h")).read()
-    return sorted(set(re.findall(r"^int\s+(sgta_\w+)\s*\(", src, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long)\s+(sgta_\w+)\s*\(", src, flags=re.M)))
 
 
 def test_header_symbols_exported_and_bound(lib):
@@ -38,7 +38,7 @@ def test_header_symbols_exported_and_bound(lib):
 def test_header_argument_counts_match_ctypes_signatures():
     from sgtapose_amd import _lib
     src = open(os.path.join(REPO, "include", "sgta_hip.h")).read()
-    for name, args in re.findall(r"^int\s+(sgta_\w+)\s*\(([^;]*?)\);", src, flags=re.M | re.S):
+    for name, args in re.findall(r"^(?:int|long)\s+(sgta_\w+)\s*\(([^;]*?)\);", src, flags=re.M | re.S):
         n = 0 if args.strip() == "void" else len([a for a in args.split(",") if a.strip()])
         assert n == len(_lib.SIGNATURES[name]), name
 
