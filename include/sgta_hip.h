@@ -408,6 +408,35 @@ int sgta_window_gather_bf16(const void* feats, long feats_bs, const long long* f
 int sgta_window_scatter_bf16(const float* tok, int ldt, const long long* fid, const unsigned char* win,
                              void* feats, long feats_bs, int B, int C, int H, int W, int n, sgta_stream_t stream);
 
+/* ---- the same 16-bit data path on IEEE half (fp16) feature maps and weights ------------------------------------------------
+ * Every ``sgta_*_bf16`` entry point above has a twin with identical arguments, layouts and reference citations whose 16-bit
+ * tensors are IEEE half instead of bfloat16 (v_mfma_f32_32x32x16_f16 / _16x16x32_f16, fp32 accumulate): 11 significant bits
+ * instead of 8, i.e. an eighth of bf16's rounding error on the head outputs, for a range of +-65504 (values beyond are
+ * clamped on store, never written as infinity).  sgta_dcnv2_fwd_f16 takes the same fp16 weights as sgta_dcnv2_fwd_bf16. */
+int sgta_conv_f16(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
+                  const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                  int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
+                  sgta_stream_t stream);
+int sgta_heads_f16(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
+                   const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0, int c1,
+                   int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                   sgta_stream_t stream);
+int sgta_dcnv2_fwd_f16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
+                       const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                       int na, int log_tw, int margin, int act, sgta_stream_t stream);
+int sgta_stem_f16(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt, const float* bias,
+                  void* y, int ldy, int B, int H, int W, sgta_stream_t stream);
+int sgta_stem_level0_f16(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
+                         const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B, int H,
+                         int W, sgta_stream_t stream);
+int sgta_maxpool2_f16(const void* x, long x_bs, void* y, long y_bs, int N, int C, int H, int W, sgta_stream_t stream);
+int sgta_upsample_add_f16(const void* x, long x_bs, const float* w, const void* skip, long skip_bs, void* y, long y_bs,
+                          int N, int C, int H, int W, int f, sgta_stream_t stream);
+int sgta_window_gather_f16(const void* feats, long feats_bs, const long long* fid, float* tok, int B, int C, int H,
+                           int W, int n, int ld, int col0, sgta_stream_t stream);
+int sgta_window_scatter_f16(const float* tok, int ldt, const long long* fid, const unsigned char* win,
+                            void* feats, long feats_bs, int B, int C, int H, int W, int n, sgta_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,16 @@ SIGNATURES = {
     "sgta_upsample_add_bf16": [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "sgta_window_gather_bf16": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_window_scatter_bf16": [_p, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
+    # the IEEE-half twins of the 16-bit data path: same arguments as their ``_bf16`` counterparts
+    "sgta_conv_f16": [_p, _l, _l, _p, _l, _p, _p, _l, _p, _l] + [_i] * 14 + [_p],
+    "sgta_dcnv2_fwd_f16": [_p, _l, _p, _i, _p, _l, _p, _p, _l] + [_i] * 9 + [_p],
+    "sgta_stem_f16": [_p, _l, _p, _l, _p, _p, _p, _i, _i, _i, _i, _p],
+    "sgta_heads_f16": [_p, _l, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p],
+    "sgta_stem_level0_f16": [_p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p],
+    "sgta_maxpool2_f16": [_p, _l, _p, _l, _i, _i, _i, _i, _p],
+    "sgta_upsample_add_f16": [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
+    "sgta_window_gather_f16": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_window_scatter_f16": [_p, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
     "sgta_pre_process": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_pnp_batched": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "sgta_gn_refine": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

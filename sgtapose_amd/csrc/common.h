@@ -52,4 +52,36 @@ __device__ __forceinline__ void xcd_remap(int bid, int inner, int& outer_id, int
   outer_id = (slot / inner) * 8 + xcd;
 }
 
+// Storage element of the 16-bit data path: bfloat16 (F16 = false: 8 significant bits, fp32's range) or IEEE half (F16 = true:
+// 11 significant bits, |x| <= 65504 -- values beyond are clamped on store, never written as infinity).  Both run on the same
+// matrix instructions' shapes with fp32 accumulation; only the operand format and the store conversion differ.
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+template <bool F16> struct H16;
+template <> struct H16<false> {
+  typedef __bf16 T;
+  typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ x4 cvt4(f32x4 v) { return __builtin_convertvector(v, x4); }
+  static __device__ __forceinline__ x8 cvt8(f32x8 v) { return __builtin_convertvector(v, x8); }
+};
+template <> struct H16<true> {
+  typedef _Float16 T;
+  typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ f32x16 mfma32(x8 a, x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mfma16(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ x4 cvt4(f32x4 v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+    return __builtin_convertvector(v, x4);
+  }
+  static __device__ __forceinline__ x8 cvt8(f32x8 v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+    return __builtin_convertvector(v, x8);
+  }
+};
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }

@@ -20,14 +20,11 @@
 #include "common.h"
 #include <cstdlib>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
 struct CbArgs {
   const void* x;    long x_bytes;  long x_bs;    // bf16 blocked input (pointer at the view's first 16-channel block), bytes reachable, elements per image
   const void* wt;   long wt_bytes;               // packed [n_ct][nchunks][taps][TC][KC] bf16, swizzled
   const float* bias;                             // [n_ct * TC]
-  const __bf16* res; long res_bs;                // residual, bf16 blocked at the output resolution (or null)
+  const void* res; long res_bs;                  // residual, 16-bit blocked at the output resolution (or null)
   void* y;          long y_bs;                   // bf16 blocked (elements per image) / fp32 NHWC (channels per pixel) / fp32 NCHW (unused)
   int N, H, W, Ho, Wo, Cout, nchunks, n_ct, n_rt, n_xt, log_tw, act, out_mode, nsig;
   // fused heads (FUSE = 1): second product W2 [<= 16 outputs] x relu(conv + bias) over ALL n_ct channel tiles of the work-group
@@ -72,10 +69,14 @@ __device__ __forceinline__ void cb_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false>
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   static_assert(!P3 || (KS == 3 && KC == 16), "the three-deep pipeline is built for 3x3 convolutions");
   using G = CbGeom<KS, S, KC, NPF>;
+  using E = H16<F16>;                                                   // element format: bf16 or IEEE half
+  typedef typename E::T elt;
+  typedef typename E::x8 bf16x8;                                        // 8 / 4 elements of the path's 16-bit format
+  typedef typename E::x4 bf16x4;
   constexpr int TC = NA * 32, TAPS = G::TAPS, KSTEPS = G::KSTEPS, P = G::P, ROWB = G::ROWB, LOG_R = G::LOG_R;
   constexpr int PAD = KS / 2;
   constexpr int WIMG = TAPS * TC * ROWB;                               // weight image bytes per (cout tile, chunk)
@@ -209,11 +210,10 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 8);
 #pragma unroll
         for (int f = 0; f < NPF; ++f) {
-          typedef float f32x8 __attribute__((ext_vector_type(8)));
           f32x8 hv;
 #pragma unroll
           for (int j = 0; j < 8; ++j) hv[j] = fmaxf(acc[i][f][8 * t + j] + (j < 4 ? b0[j & 3] : b1[j & 3]), 0.0f);
-          acc2[FUSE ? f : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, __builtin_convertvector(hv, bf16x8), acc2[FUSE ? f : 0], 0, 0, 0);
+          acc2[FUSE ? f : 0] = E::mfma32(a2, E::cvt8(hv), acc2[FUSE ? f : 0]);
         }
       }
 #pragma unroll
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
           for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int f = 0; f < NPF; ++f)
-              acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tl & 1][i], bfr[tl & 1][f], acc[i][f], 0, 0, 0);
+              acc[i][f] = E::mfma32(afr[tl & 1][i], bfr[tl & 1][f], acc[i][f]);
         }
       }
       if (FUSE && nkc == 0) heads_tile();
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int f = 0; f < NPF; ++f)
-          acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[k & 1][i], bfr[k & 1][f], acc[i][f], 0, 0, 0);
+          acc[i][f] = E::mfma32(afr[k & 1][i], bfr[k & 1][f], acc[i][f]);
       if (more) {
 #pragma unroll
         for (int d = 0; d < DPK; ++d)
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = acc[i][f][4 * g4 + j] + bv[j];
       if (a.res) {
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + (long)pn[f] * a.res_bs + (long)(co0 >> 4) * HWo * 16 +
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const elt*>(a.res) + (long)pn[f] * a.res_bs + (long)(co0 >> 4) * HWo * 16 +
                                                            (long)prem[f] * 16 + (co0 & 15));
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
@@ -400,14 +400,14 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const bf16x4 pb = __builtin_convertvector(value4(i, f, 2 * m), bf16x4);
-          const bf16x4 qb = __builtin_convertvector(value4(i, f, 2 * m + 1), bf16x4);
+          const bf16x4 pb = E::cvt4(value4(i, f, 2 * m));
+          const bf16x4 qb = E::cvt4(value4(i, f, 2 * m + 1));
           const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
           const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
           const int co = ct * TC + i * 32 + 16 * m + 8 * h;
           if (co < a.Cout)                       // blocked: block co >> 4, the lane's half (8 h) of the pixel's 16-channel run
-            *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(a.y) + (long)pn[f] * a.y_bs + (long)(co >> 4) * HWo * 16 +
+            *reinterpret_cast<u32x4*>(reinterpret_cast<elt*>(a.y) + (long)pn[f] * a.y_bs + (long)(co >> 4) * HWo * 16 +
                                       (long)prem[f] * 16 + (co & 15)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
         }
       continue;
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
         if (co0 >= a.Cout) continue;
         const f32x4 v = value4(i, f, g4);
         if (a.out_mode == 0) {
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.y) + (long)pn[f] * a.y_bs + (long)(co0 >> 4) * HWo * 16 +
-                                     (long)prem[f] * 16 + (co0 & 15)) = __builtin_convertvector(v, bf16x4);
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<elt*>(a.y) + (long)pn[f] * a.y_bs + (long)(co0 >> 4) * HWo * 16 +
+                                     (long)prem[f] * 16 + (co0 & 15)) = E::cvt4(v);
         } else if (a.out_mode == 2) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pix * a.y_bs + co0) = v;
         } else {
@@ -434,14 +434,14 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   }
 }
 
-template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false>
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false>
 static int cb_launch(CbArgs& a, hipStream_t st) {
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int WIMG = KS * KS * NA * 32 * KC * 2;
   constexpr int LDS = P3 ? 2 * G::WIN_BYTES + 3 * ((3 * NA * 32 * KC * 2 + 8191) / 8192) * 8192
                          : 2 * (G::WIN_BYTES + ((WIMG + 8191) / 8192) * 8192);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE, P3>;
+  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE, P3, F16>;
   static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
   bool& done = attr_by_dev[sgta_device_slot()];
   if (!done) {
@@ -471,10 +471,11 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
 // [N,Ho,Wo,y_bs], 1: y f32 NCHW [N,Cout,Ho,Wo] with sigmoid on channels < nsig.  act: 0 none, 1 ReLU.
 // npf: 32-position fragments per wave (2: 512-position tiles; 1: 256; stride 2 needs 1); log_tw: log2 of the tile width
 // (3..6).  Cin % kc == 0, kc in {16 (3x3), 32 (1x1)}.
-extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
-                              const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
-                              int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
-                              hipStream_t st) {
+template <bool F16>
+static int cb_conv(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
+                   const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                   int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
+                   hipStream_t st) {
   if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SGTA_EBADARG;
   if (x_bytes <= 0 || x_bytes > 0x7fffffffL || wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if (Cin % kc || (x_bs % 16) || ((uintptr_t)x & 15) || log_tw < 3 || log_tw > 6 || act < 0 || act > 1 || out_mode < 0 ||
@@ -485,7 +486,7 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
   if (res && (res_bs % 16 || ((uintptr_t)res & 7))) return SGTA_EBADARG;
   CbArgs a{};
   a.x = x; a.x_bytes = x_bytes; a.x_bs = x_bs; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
-  a.res = reinterpret_cast<const __bf16*>(res); a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
+  a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cout = Cout;
   a.nchunks = Cin / kc; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act; a.out_mode = out_mode; a.nsig = nsig;
   if (npf != 1 && npf != 2) return SGTA_EBADARG;
@@ -494,27 +495,44 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
   a.n_xt = cdiv(a.Wo, TW);
   static const bool p3 = sgta_tool_env("SGTA_CONV_P3", 1) != 0;   // tools: 0 = the two-stage loop
   if (ks == 3 && stride == 1 && kc == 16 && npf == 2) {
-    if (na == 1) return p3 ? cb_launch<3, 1, 16, 2, 1, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 1>(a, st);
-    if (na == 2) return p3 ? cb_launch<3, 1, 16, 2, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 2>(a, st);
-    if (na == 4) return p3 ? cb_launch<3, 1, 16, 2, 4, 0, true>(a, st) : cb_launch<3, 1, 16, 2, 4>(a, st);
+    if (na == 1) return p3 ? cb_launch<3, 1, 16, 2, 1, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 2, 1, 0, false, F16>(a, st);
+    if (na == 2) return p3 ? cb_launch<3, 1, 16, 2, 2, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 2, 2, 0, false, F16>(a, st);
+    if (na == 4) return p3 ? cb_launch<3, 1, 16, 2, 4, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 2, 4, 0, false, F16>(a, st);
   } else if (ks == 3 && stride == 1 && kc == 16 && npf == 1) {       // half-size tiles: small maps (work-group count / tail)
-    if (na == 1) return p3 ? cb_launch<3, 1, 16, 1, 1, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 1>(a, st);
-    if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 2>(a, st);
-    if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true>(a, st) : cb_launch<3, 1, 16, 1, 4>(a, st);
+    if (na == 1) return p3 ? cb_launch<3, 1, 16, 1, 1, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 1, 1, 0, false, F16>(a, st);
+    if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 1, 2, 0, false, F16>(a, st);
+    if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 1, 4, 0, false, F16>(a, st);
   } else if (ks == 3 && stride == 2 && kc == 16 && npf == 1) {
     static const bool p3s2 = sgta_tool_env("SGTA_CONV_P3S2", 0) == 1;
-    if (na == 1) return p3s2 ? cb_launch<3, 2, 16, 1, 1, 0, true>(a, st) : cb_launch<3, 2, 16, 1, 1>(a, st);
-    if (na == 2) return p3s2 ? cb_launch<3, 2, 16, 1, 2, 0, true>(a, st) : cb_launch<3, 2, 16, 1, 2>(a, st);
+    if (na == 1) return p3s2 ? cb_launch<3, 2, 16, 1, 1, 0, true, F16>(a, st) : cb_launch<3, 2, 16, 1, 1, 0, false, F16>(a, st);
+    if (na == 2) return p3s2 ? cb_launch<3, 2, 16, 1, 2, 0, true, F16>(a, st) : cb_launch<3, 2, 16, 1, 2, 0, false, F16>(a, st);
   } else if (ks == 1 && stride == 1 && kc == 32 && npf == 2) {
-    if (na == 1) return cb_launch<1, 1, 32, 2, 1>(a, st);
-    if (na == 2) return cb_launch<1, 1, 32, 2, 2>(a, st);
-    if (na == 4) return cb_launch<1, 1, 32, 2, 4>(a, st);
+    if (na == 1) return cb_launch<1, 1, 32, 2, 1, 0, false, F16>(a, st);
+    if (na == 2) return cb_launch<1, 1, 32, 2, 2, 0, false, F16>(a, st);
+    if (na == 4) return cb_launch<1, 1, 32, 2, 4, 0, false, F16>(a, st);
   } else if (ks == 1 && stride == 1 && kc == 32 && npf == 1) {
-    if (na == 1) return cb_launch<1, 1, 32, 1, 1>(a, st);
-    if (na == 2) return cb_launch<1, 1, 32, 1, 2>(a, st);
-    if (na == 4) return cb_launch<1, 1, 32, 1, 4>(a, st);
+    if (na == 1) return cb_launch<1, 1, 32, 1, 1, 0, false, F16>(a, st);
+    if (na == 2) return cb_launch<1, 1, 32, 1, 2, 0, false, F16>(a, st);
+    if (na == 4) return cb_launch<1, 1, 32, 1, 4, 0, false, F16>(a, st);
   }
   return SGTA_EBADARG;
+}
+
+extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
+                              const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                              int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
+                              hipStream_t st) {
+  return cb_conv<false>(x, x_bytes, x_bs, wt, wt_bytes, bias, res, res_bs, y, y_bs, N, H, W, Cin, Cout, ks, stride, kc, na, npf,
+                        log_tw, act, out_mode, nsig, st);
+}
+
+// The same convolution on IEEE-half feature maps and weights (v_mfma_f32_32x32x16_f16): identical layouts and arguments.
+extern "C" int sgta_conv_f16(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
+                             const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                             int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
+                             hipStream_t st) {
+  return cb_conv<true>(x, x_bytes, x_bs, wt, wt_bytes, bias, res, res_bs, y, y_bs, N, H, W, Cin, Cout, ks, stride, kc, na, npf,
+                       log_tw, act, out_mode, nsig, st);
 }
 
 // The three head branches in one kernel (base_model.py:121-135): hidden = relu(conv3x3(x) + b1) with the branches' 3x3 convs
@@ -523,10 +541,11 @@ extern "C" int sgta_conv_bf16(const void* x, long x_bytes, long x_bs, const void
 // sigmoid on rows < nsig.  w2: bf16 A fragments [Chid/128][4][2][64 lanes][8] of the second v_mfma_f32_32x32x16_bf16: lane
 // (m = lane & 31, h = lane >> 5), element j of k-step t of 32-channel block i holds W2[m][128 ct + 32 i + 8 (2t + (j >> 2)) +
 // 4h + (j & 3)] (zero for m >= the number of rows).  npf / log_tw as sgta_conv_bf16.  Cin % 16 == 0, Chid % 128 == 0.
-extern "C" int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
-                               const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0,
-                               int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
-                               hipStream_t st) {
+template <bool F16>
+static int cb_heads(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
+                    const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0,
+                    int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                    hipStream_t st) {
   if (!x || !w1 || !b1 || !w2 || !b2 || !out0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Chid <= 0) return SGTA_EBADARG;
   if (x_bytes <= 0 || x_bytes > 0x7fffffffL || w1_bytes <= 0 || w1_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if (Cin % 16 || Chid % 128 || (x_bs % 16) || ((uintptr_t)x & 15) || ((uintptr_t)w2 & 15) || log_tw < 3 || log_tw > 6) return SGTA_EBADARG;
@@ -543,7 +562,23 @@ extern "C" int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const voi
   a.n_xt = cdiv(W, TW);
   // (the two-stage loop: with six channel tiles per work-group and no output tensor its waits are already hidden, and the
   // three-deep form's extra barriers cost it 9 % here)
-  if (npf == 2) return cb_launch<3, 1, 16, 2, 4, 1>(a, st);
-  if (npf == 1) return cb_launch<3, 1, 16, 1, 4, 1>(a, st);
+  if (npf == 2) return cb_launch<3, 1, 16, 2, 4, 1, false, F16>(a, st);
+  if (npf == 1) return cb_launch<3, 1, 16, 1, 4, 1, false, F16>(a, st);
   return SGTA_EBADARG;
+}
+
+extern "C" int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
+                               const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0,
+                               int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                               hipStream_t st) {
+  return cb_heads<false>(x, x_bytes, x_bs, w1, w1_bytes, b1, w2, b2, out0, out1, out2, out3, c0, c1, c2, c3, N, H, W, Cin, Chid,
+                         npf, log_tw, nsig, st);
+}
+
+extern "C" int sgta_heads_f16(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
+                              const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0,
+                              int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                              hipStream_t st) {
+  return cb_heads<true>(x, x_bytes, x_bs, w1, w1_bytes, b1, w2, b2, out0, out1, out2, out3, c0, c1, c2, c3, N, H, W, Cin, Chid,
+                        npf, log_tw, nsig, st);
 }

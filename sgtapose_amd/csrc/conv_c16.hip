@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
 // MODE 0: both stems fused (default).  Sequence mode (the image stem of frame t, computed when
 // t is the current frame, is reused when t is the previous frame): MODE 1 = image stem only, y = relu(bn(conv7x7(img)));
 // MODE 2 = heat-map stem only plus the cached image stem, y = a.x (cached [B,16,H,W]) + relu(bn(conv7x7(hm))).
-template <bool NHWC_BF16, int MODE = 0>
+template <bool NHWC_BF16, int MODE = 0, bool F16 = false>
 __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
   constexpr int KS = 7, TH = 8, TW = 32, KK = 49, P = 3;
   constexpr int WH = TH + KS - 1, WW = TW + KS - 1;
@@ -235,15 +235,16 @@ __global__ __launch_bounds__(256) void stem_c16_kernel(C16Args a) {
     const int y = ty0 + 2 * wave + (n >> 1), x = tx0 + (n & 1) * 16 + c16;
     if (y >= H || x >= W) continue;
     if (NHWC_BF16) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      typedef typename H16<F16>::T elt;                  // bf16, or IEEE half for the f16 data path
+      typedef typename H16<F16>::x4 bf16x4;
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = 4 * g + r;
         v[r] = fmaxf(acc[0][n][r] + a.bias[co], 0.0f) + fmaxf(acc[1][n][r] + a.bias[16 + co], 0.0f);
       }
-      __bf16* yh = reinterpret_cast<__bf16*>(a.y) + (((long)b * H + y) * W + x) * a.y_bs + 4 * g;
-      *reinterpret_cast<bf16x4*>(yh) = __builtin_convertvector(v, bf16x4);
+      elt* yh = reinterpret_cast<elt*>(a.y) + (((long)b * H + y) * W + x) * a.y_bs + 4 * g;
+      *reinterpret_cast<bf16x4*>(yh) = H16<F16>::cvt4(v);
       continue;
     }
     float* yb = a.y + (long)b * a.y_bs + y * W + x;
@@ -289,6 +290,17 @@ extern "C" int sgta_stem_bf16(const float* x, long x_bs, const float* x2, long x
   if ((long)16 * H * W > 0x7fffffffL) return SGTA_EBADARG;
   C16Args a{x, x_bs, x2, x2_bs, wt, bias, reinterpret_cast<float*>(y), (long)ldy, B, H, W, cdiv(W, 32), cdiv(H, 8)};
   hipLaunchKernelGGL(stem_c16_kernel<true>, dim3(B * a.tiles_x * a.tiles_y), dim3(256), 0, st, a);
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}
+
+// The same stems with an IEEE-half output (the f16 data path).
+extern "C" int sgta_stem_f16(const float* x, long x_bs, const float* x2, long x2_bs, const float* wt, const float* bias,
+                             void* y, int ldy, int B, int H, int W, hipStream_t st) {
+  if (!x || !x2 || !wt || !bias || !y || B <= 0 || H <= 0 || W <= 0 || ldy < 16 || ldy % 4) return SGTA_EBADARG;
+  if ((long)16 * H * W > 0x7fffffffL) return SGTA_EBADARG;
+  C16Args a{x, x_bs, x2, x2_bs, wt, bias, reinterpret_cast<float*>(y), (long)ldy, B, H, W, cdiv(W, 32), cdiv(H, 8)};
+  hipLaunchKernelGGL((stem_c16_kernel<true, 0, true>), dim3(B * a.tiles_x * a.tiles_y), dim3(256), 0, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

@@ -10,17 +10,15 @@
 // channels of the work-group.  Accumulation fp32 on v_mfma_f32_32x32x16_f16 (weights and blended samples fp16, see below).
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct DbArgs {
-  const __bf16* x;  long x_bs;  long x_bytes;    // bf16 blocked input [N][Cb][H][W][16] (pointer at the view's first block), elements per image, extent
+  const void* x;    long x_bs;  long x_bytes;    // bf16 / fp16 blocked input [N][Cb][H][W][16] (pointer at the view's first block), elements per image, extent
   const float* om;  int ldo;                     // f32 NHWC offsets / mask logits [N,H,W,ldo]: ldo >= 28, ldo % 4 == 0 (read as 7 x 16 bytes)
   const void* wt;   long wt_bytes;               // packed [n_ct][Cin/16][9][TC][16] FP16, swizzled
   const float* bias;                             // [n_ct * TC]
-  __bf16* y;        long y_bs;                   // bf16 blocked output, elements per image
+  void* y;          long y_bs;                   // bf16 / fp16 blocked output, elements per image
   int N, H, W, Cin, Cout, ngroups, n_ct, n_rt, n_xt, log_tw, act;
   unsigned mH, mWC[3];                           // ceil(2^32 / H), ceil(2^32 / window columns) for log_tw 3..5 (umulhi division)
 };
@@ -79,9 +77,14 @@ struct DbGeom {
   static constexpr int AUX_BYTES = PR ? (PT_MAX * 4 + 16 + 15) / 16 * 16 : 0;
 };
 
-template <int NA, int R, int PR>
+// F16: the feature maps are IEEE half instead of bf16 -- the staged window needs no conversion, the rest is unchanged.
+template <int NA, int R, int PR, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   using G = DbGeom<R, PR>;
+  using E = H16<F16>;
+  typedef typename E::T elt;
+  typedef typename E::x8 bf16x8;                             // 8 / 4 elements of the maps' format
+  typedef typename E::x4 bf16x4;
   constexpr int TC = NA * 32, TP = 128, ROWB = 32, NT = 256;
   constexpr int WIMG = 9 * TC * ROWB, AROUNDS = (WIMG + NT * 16 - 1) / (NT * 16);
   constexpr int WROUNDS = G::WROUNDS, WIN_BYTES = G::WIN_BYTES;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
   __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), (short)0, (int)a.wt_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
 #endif
   const int nchunks = a.Cin / 16;
   auto stage = [&](int kc) {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
         if (DB_ABLATE != 5) stage(kc);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (DB_ABLATE != 4) convert_window(Ws);      // own pieces only: no barrier needed between the DMA wait and this
+      if (DB_ABLATE != 4 && !F16) convert_window(Ws);      // own pieces only: no barrier needed between the DMA wait and this
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                // window (converted) + weights of chunk kc complete for all waves
 #pragma unroll
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
         stage(kc);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      convert_window(Ws);
+      if (!F16) convert_window(Ws);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll 1
@@ -413,26 +416,26 @@ __global__ __launch_bounds__(256, 2) void dcn_bf16_kernel(DbArgs a) {
     for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const bf16x4 pb = __builtin_convertvector(value4(i, 2 * m), bf16x4);
-        const bf16x4 qb = __builtin_convertvector(value4(i, 2 * m + 1), bf16x4);
+        const bf16x4 pb = E::cvt4(value4(i, 2 * m));
+        const bf16x4 qb = E::cvt4(value4(i, 2 * m + 1));
         const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
         const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
         const int co = ct * TC + i * 32 + 16 * m + 8 * h;
         if (co < a.Cout)
-          *reinterpret_cast<u32x4*>(a.y + (long)n * a.y_bs + (long)(co >> 4) * H * W * 16 + ((long)yp * W + xp) * 16 + (co & 15)) =
+          *reinterpret_cast<u32x4*>(reinterpret_cast<elt*>(a.y) + (long)n * a.y_bs + (long)(co >> 4) * H * W * 16 + ((long)yp * W + xp) * 16 + (co & 15)) =
               u32x4{s0[0], s1[0], s0[1], s1[1]};
       }
   }
 }
 
-template <int NA, int R, int PR>
+template <int NA, int R, int PR, bool F16>
 static int db_launch(DbArgs& a, hipStream_t st) {
   using G = DbGeom<R, PR>;
   constexpr int NT = 256, WIMG = 9 * NA * 32 * 32;
   constexpr int LDS = G::WIN_BYTES + (WIMG + NT * 16 - 1) / (NT * 16) * NT * 16 + G::AUX_BYTES;
   static_assert(2 * LDS <= 160 * 1024, "two work-groups per CU");
-  auto kern = dcn_bf16_kernel<NA, R, PR>;
+  auto kern = dcn_bf16_kernel<NA, R, PR, F16>;
   if (LDS > 64 * 1024) {
     static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
     bool& done = attr_by_dev[sgta_device_slot()];
@@ -459,9 +462,10 @@ static int db_launch(DbArgs& a, hipStream_t st) {
 // sgta_conv_bf16, ops_bf16.py); bias f32 [n_ct*32*na] (BN folded); y bf16 blocked (y_bs elements per image); act 1 = ReLU.
 // Cin % 16 == 0, Cout % 8 == 0.  margin: 6 (window of +-6 pixels round the tile, log_tw in 3..5) or 10 (+-10 pixels and patch
 // slots for the samples beyond, log_tw in 3..4): speed only, every margin gives the same result.
-extern "C" int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
-                                   const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
-                                   int na, int log_tw, int margin, int act, hipStream_t st) {
+template <bool F16>
+static int db_dcn(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
+                  const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                  int na, int log_tw, int margin, int act, hipStream_t st) {
   if (!x || !om || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
   if (Cin % 16 || Cout % 8 || x_bs % 16 || y_bs % 16 || ((uintptr_t)y & 15) || ((uintptr_t)x & 15) || ldo < 28 || ldo % 4 || ((uintptr_t)om & 15) || log_tw < 3 ||
       log_tw > 5 || (margin != 6 && margin != 10) || (margin == 10 && log_tw > 4))
@@ -469,11 +473,24 @@ extern "C" int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, in
   if (wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if ((long)N * x_bs * 2 > 0x7fffffffL) return SGTA_EBADARG;             // 31-bit byte offsets in the gather
   DbArgs a;
-  a.x = reinterpret_cast<const __bf16*>(x); a.x_bs = x_bs;
+  a.x = x; a.x_bs = x_bs;
   a.x_bytes = ((long)(N - 1) * x_bs + (long)(Cin / 16) * H * W * 16) * 2; a.om = om; a.ldo = ldo; a.wt = wt; a.wt_bytes = wt_bytes;
-  a.bias = bias; a.y = reinterpret_cast<__bf16*>(y); a.y_bs = y_bs; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.bias = bias; a.y = y; a.y_bs = y_bs; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.ngroups = Cin / 16; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act;
-  if (na == 2) return margin == 6 ? db_launch<2, 6, 0>(a, st) : db_launch<2, 10, 4>(a, st);
-  if (na == 4) return margin == 6 ? db_launch<4, 6, 0>(a, st) : db_launch<4, 10, 4>(a, st);
+  if (na == 2) return margin == 6 ? db_launch<2, 6, 0, F16>(a, st) : db_launch<2, 10, 4, F16>(a, st);
+  if (na == 4) return margin == 6 ? db_launch<4, 6, 0, F16>(a, st) : db_launch<4, 10, 4, F16>(a, st);
   return SGTA_EBADARG;
+}
+
+extern "C" int sgta_dcnv2_fwd_bf16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
+                                   const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                                   int na, int log_tw, int margin, int act, hipStream_t st) {
+  return db_dcn<false>(x, x_bs, om, ldo, wt, wt_bytes, bias, y, y_bs, N, H, W, Cin, Cout, na, log_tw, margin, act, st);
+}
+
+// The same operator on IEEE-half feature maps (x, y fp16 blocked): the staged window is used as it arrives.
+extern "C" int sgta_dcnv2_fwd_f16(const void* x, long x_bs, const float* om, int ldo, const void* wt, long wt_bytes,
+                                  const float* bias, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
+                                  int na, int log_tw, int margin, int act, hipStream_t st) {
+  return db_dcn<true>(x, x_bs, om, ldo, wt, wt_bytes, bias, y, y_bs, N, H, W, Cin, Cout, na, log_tw, margin, act, st);
 }

@@ -22,19 +22,17 @@
 // The input image is rounded to bf16 once (2^-9 relative, like every other activation of this path); accumulation fp32.
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct SlArgs {
   const float* img; long img_bs;
   const float* hm;  long hm_bs;
-  const bf16x8* w_stem;              // [7 k-steps (ky)][2: image stem, prior stem][64 lanes] A fragments
+  const void* w_stem;                // [7 k-steps (ky)][2: image stem, prior stem][64 lanes] A fragments (8 elements each)
   const float* b_stem;               // [32]: image stem 0..15, prior stem 16..31 (folded BN)
-  const bf16x8* w_l0;                // [5 k-steps][64 lanes]
+  const void* w_l0;                  // [5 k-steps][64 lanes]
   const float* b_l0;                 // [16]
-  __bf16* y; long y_bs;
+  void* y; long y_bs;
   int B, H, W, n_ty, n_tx;
 };
 
@@ -48,8 +46,14 @@ constexpr int STEM_BYTES = SPX * 32;                     // 38,016
 constexpr int N_SPAIR = (SPX + 31) / 32;                 // pairs of 16-pixel groups of the stem region (38)
 }  // namespace sl
 
+// F16: IEEE half instead of bf16 for the staged input, the stem region, the weights and the output (v_mfma_f32_16x16x32_f16).
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
   using namespace sl;
+  using E = H16<F16>;
+  typedef typename E::T elt;
+  typedef typename E::x8 bf16x8;
+  typedef typename E::x4 bf16x4;
   __shared__ __attribute__((aligned(16))) unsigned char lds[WIN_BYTES + STEM_BYTES];
   unsigned char* const win = lds;
   unsigned char* const stem = lds + WIN_BYTES;
@@ -77,8 +81,7 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<bf16x4*>(win + (r * WS + 4 * q + i) * 8) =
-          __builtin_convertvector(f32x4{v[0][i], v[1][i], v[2][i], v[3][i]}, bf16x4);
+      *reinterpret_cast<bf16x4*>(win + (r * WS + 4 * q + i) * 8) = E::cvt4(f32x4{v[0][i], v[1][i], v[2][i], v[3][i]});
   }
   if (tid < 4 * WH)                                         // columns 72..79: read by the zero-weight 8th tap, must be finite
     *reinterpret_cast<u32x4*>(win + ((tid >> 2) * WS + WW) * 8 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -87,11 +90,11 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
   bf16x8 ws[7][2], wl[5];
 #pragma unroll
   for (int s = 0; s < 7; ++s) {
-    ws[s][0] = a.w_stem[(2 * s) * 64 + lane];
-    ws[s][1] = a.w_stem[(2 * s + 1) * 64 + lane];
+    ws[s][0] = reinterpret_cast<const bf16x8*>(a.w_stem)[(2 * s) * 64 + lane];
+    ws[s][1] = reinterpret_cast<const bf16x8*>(a.w_stem)[(2 * s + 1) * 64 + lane];
   }
 #pragma unroll
-  for (int s = 0; s < 5; ++s) wl[s] = a.w_l0[s * 64 + lane];
+  for (int s = 0; s < 5; ++s) wl[s] = reinterpret_cast<const bf16x8*>(a.w_l0)[s * 64 + lane];
   const int c4 = 4 * (((kg & 1) << 1) | (kg >> 1));        // first of this lane's 4 output channels (rows 4 kg .. 4 kg + 3)
   const f32x4 bi = *reinterpret_cast<const f32x4*>(a.b_stem + c4);
   const f32x4 bh = *reinterpret_cast<const f32x4*>(a.b_stem + 16 + c4);
@@ -119,8 +122,8 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
         const unsigned char* src = win + base[u] + s * (WS * 8);
         const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 8);
         const bf16x8 x = __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]});
-        ai[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[s][0], x, ai[u], 0, 0, 0);
-        ah[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws[s][1], x, ah[u], 0, 0, 0);
+        ai[u] = E::mfma16(ws[s][0], x, ai[u]);
+        ah[u] = E::mfma16(ws[s][1], x, ah[u]);
       }
     u32x2 v[2];
 #pragma unroll
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
         r[i] = fmaxf(ai[u][i] + bi[i], 0.0f) + fmaxf(ah[u][i] + bh[i], 0.0f);
         if (!inside[u]) r[i] = 0.0f;                                      // level0's zero padding
       }
-      v[u] = __builtin_bit_cast(u32x2, __builtin_convertvector(r, bf16x4));
+      v[u] = __builtin_bit_cast(u32x2, E::cvt4(r));
     }
     const auto s0 = __builtin_amdgcn_permlane32_swap(v[0][0], v[1][0], false, false);
     const auto s1 = __builtin_amdgcn_permlane32_swap(v[0][1], v[1][1], false, false);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
     const int tt = t < 9 ? t : 0;
     toff[s] = (tt / 3) * SW + tt % 3;
   }
-  __bf16* const yb = a.y + (long)b * a.y_bs;
+  elt* const yb = reinterpret_cast<elt*>(a.y) + (long)b * a.y_bs;
 #pragma unroll 2
   for (int j = 0; j < (TH * TW / 32) / 4; ++j) {
     const int pr = wave * ((TH * TW / 32) / 4) + j;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
       for (int u = 0; u < 2; ++u) {
         const int px = oy * SW + oxa + 16 * u + n + toff[s];
         const bf16x8 x = *reinterpret_cast<const bf16x8*>(stem + px * 32 + (((kg & 1) ^ ((px >> 3) & 1)) << 4));
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], x, acc[u], 0, 0, 0);
+        acc[u] = E::mfma16(wl[s], x, acc[u]);
       }
     u32x2 v[2];
 #pragma unroll
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
       f32x4 r;
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = fmaxf(acc[u][i] + bl[i], 0.0f);
-      v[u] = __builtin_bit_cast(u32x2, __builtin_convertvector(r, bf16x4));
+      v[u] = __builtin_bit_cast(u32x2, E::cvt4(r));
     }
     const auto s0 = __builtin_amdgcn_permlane32_swap(v[0][0], v[1][0], false, false);
     const auto s1 = __builtin_amdgcn_permlane32_swap(v[0][1], v[1][1], false, false);
@@ -179,9 +182,10 @@ __global__ __launch_bounds__(256, 3) void stem_l0_bf16_kernel(SlArgs a) {
   }
 }
 
-extern "C" int sgta_stem_level0_bf16(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
-                                     const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B,
-                                     int H, int W, hipStream_t st) {
+template <bool F16>
+static int sl_entry(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
+                    const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B,
+                    int H, int W, hipStream_t st) {
   if (!img || !hm || !w_stem || !b_stem || !w_l0 || !b_l0 || !y || B <= 0 || H <= 0 || W <= 0) return SGTA_EBADARG;
   // float4 window loads: rows and planes of both inputs must be 16-byte aligned
   if (W % 4 || img_bs % 4 || hm_bs % 4 || ((uintptr_t)img & 15) || ((uintptr_t)hm & 15) || ((uintptr_t)y & 15) || y_bs % 8)
@@ -189,13 +193,25 @@ extern "C" int sgta_stem_level0_bf16(const float* img, long img_bs, const float*
   if (((uintptr_t)w_stem & 15) || ((uintptr_t)w_l0 & 15) || ((uintptr_t)b_stem & 15) || ((uintptr_t)b_l0 & 15)) return SGTA_EBADARG;
   SlArgs a{};
   a.img = img; a.img_bs = img_bs; a.hm = hm; a.hm_bs = hm_bs;
-  a.w_stem = reinterpret_cast<const bf16x8*>(w_stem); a.b_stem = b_stem;
-  a.w_l0 = reinterpret_cast<const bf16x8*>(w_l0); a.b_l0 = b_l0;
-  a.y = reinterpret_cast<__bf16*>(y); a.y_bs = y_bs; a.B = B; a.H = H; a.W = W;
+  a.w_stem = w_stem; a.b_stem = b_stem;
+  a.w_l0 = w_l0; a.b_l0 = b_l0;
+  a.y = y; a.y_bs = y_bs; a.B = B; a.H = H; a.W = W;
   a.n_ty = cdiv(H, sl::TH); a.n_tx = cdiv(W, sl::TW);
   const long blocks = (long)B * a.n_ty * a.n_tx;
   if (blocks > 0x7fffffffL) return SGTA_EBADARG;
-  hipLaunchKernelGGL(stem_l0_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(stem_l0_bf16_kernel<F16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
+}
+
+extern "C" int sgta_stem_level0_bf16(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
+                                     const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B,
+                                     int H, int W, hipStream_t st) {
+  return sl_entry<false>(img, img_bs, hm, hm_bs, w_stem, b_stem, w_l0, b_l0, y, y_bs, B, H, W, st);
+}
+
+extern "C" int sgta_stem_level0_f16(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem,
+                                    const float* b_stem, const void* w_l0, const float* b_l0, void* y, long y_bs, int B,
+                                    int H, int W, hipStream_t st) {
+  return sl_entry<true>(img, img_bs, hm, hm_bs, w_stem, b_stem, w_l0, b_l0, y, y_bs, B, H, W, st);
 }

@@ -20,6 +20,11 @@ from .ops_bf16 import BF16, PackedConvBF16, PackedDCNBF16, ViewH
 
 class EngineBF16(Engine):
     dtype = "bf16"
+    act_dtype = BF16          # element format of the feature maps and weights (EngineF16: IEEE half)
+
+    def __init__(self, model):
+        with bops.pack_dtype(self.act_dtype):
+            super().__init__(model)
     fuse_heads = True         # sgta_heads_bf16: the 3x3 -> ReLU -> 1x1 branches in one kernel, no hidden tensor in memory
     fuse_stem = True          # sgta_stem_level0_bf16 (bf16 MFMA, stem map in LDS) instead of the f32 stem kernel + level0 conv
 
@@ -86,10 +91,10 @@ class EngineBF16(Engine):
     split_parts = 2               # chain of launches with 1.2-round tails and latency-bound prologues; independent slices
     #                               side by side fill those gaps (measured: -3 % on the step)
 
-    def hbuf(self, name, n, h, w, c, dtype=BF16):
-        """bf16 maps: blocked [n, c/16, h, w, 16]; fp32 maps (DCN offsets): plain channels-last [n, h, w, c]."""
-        if dtype == BF16:
-            return ViewH(self.buf(name, (n, c // 16, h, w, 16), dtype))
+    def hbuf(self, name, n, h, w, c, dtype=None):
+        """16-bit maps: blocked [n, c/16, h, w, 16]; fp32 maps (DCN offsets): plain channels-last [n, h, w, c]."""
+        if dtype is None:
+            return ViewH(self.buf(name, (n, c // 16, h, w, 16), self.act_dtype))
         return ViewH(self.buf(name, (n, h, w, c), dtype))
 
     @staticmethod
@@ -327,3 +332,11 @@ class EngineBF16(Engine):
             out[name] = o
             off += hc
         return out
+
+
+class EngineF16(EngineBF16):
+    """The same engine on IEEE-half feature maps and weights (C ABI ``sgta_*_f16``): 11 significant bits instead of bf16's 8
+    at the same bytes and matrix rate -- head outputs within a few 1e-3 of the fp32 path instead of a few 1e-2 -- for a
+    range of +-65504 (clamped on store).  ``model.engine_dtype = "f16"``."""
+    dtype = "f16"
+    act_dtype = bops.F16

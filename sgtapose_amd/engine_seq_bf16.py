@@ -116,3 +116,9 @@ class EngineSeqBF16(EngineBF16):
             if side is not None:
                 main.wait_stream(side)
             return out
+
+
+class EngineSeqF16(EngineSeqBF16):
+    """The same engine on IEEE-half feature maps and weights (engine_bf16.EngineF16)."""
+    dtype = "f16"
+    act_dtype = torch.float16

@@ -92,3 +92,9 @@ class EngineThreeBF16(EngineBF16):
             if side is not None:
                 main.wait_stream(side)
             return out
+
+
+class EngineThreeF16(EngineThreeBF16):
+    """The same engine on IEEE-half feature maps and weights (engine_bf16.EngineF16)."""
+    dtype = "f16"
+    act_dtype = torch.float16

@@ -234,24 +234,25 @@ class DLAPlanAWindowL3New(nn.Module):
             raise RuntimeError("the HIP path is inference-only: call model.eval() (sgta_detector.py:54)")
         return [self.engine().forward(x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls)]
 
-    # 'f32' (the reference's arithmetic, BASELINE configs[1]) or 'bf16' (configs[2]: bf16 feature maps / weights on bf16
-    # MFMA, fp32 accumulate / softmax / LayerNorm / decode); also read from opt.compute_dtype at construction
+    # 'f32' (the reference's arithmetic, BASELINE configs[1]), 'bf16' (configs[2]: bf16 feature maps / weights on bf16
+    # MFMA, fp32 accumulate / softmax / LayerNorm / decode) or 'f16' (the same data path on IEEE half: an eighth of bf16's
+    # rounding error at the same speed, range +-65504); also read from opt.compute_dtype at construction
     @property
     def engine_dtype(self):
         return getattr(self, "_engine_dtype", getattr(self.opt, "compute_dtype", "f32"))
 
     @engine_dtype.setter
     def engine_dtype(self, v):
-        if v not in ("f32", "bf16"):
-            raise ValueError("engine_dtype must be 'f32' or 'bf16'")
+        if v not in ("f32", "bf16", "f16"):
+            raise ValueError("engine_dtype must be 'f32', 'bf16' or 'f16'")
         object.__setattr__(self, "_engine_dtype", v)
         self._engine = None
 
     def engine(self):
         if self._engine is None:
-            if self.engine_dtype == "bf16":
-                from ..engine_bf16 import EngineBF16
-                self._engine = EngineBF16(self)
+            if self.engine_dtype in ("bf16", "f16"):
+                from ..engine_bf16 import EngineBF16, EngineF16
+                self._engine = (EngineF16 if self.engine_dtype == "f16" else EngineBF16)(self)
             else:
                 from ..engine import Engine
                 self._engine = Engine(self)
@@ -344,16 +345,16 @@ class DLAPlanAWindowThree(nn.Module):
 
     @engine_dtype.setter
     def engine_dtype(self, v):
-        if v not in ("f32", "bf16"):
-            raise ValueError("engine_dtype must be 'f32' or 'bf16'")
+        if v not in ("f32", "bf16", "f16"):
+            raise ValueError("engine_dtype must be 'f32', 'bf16' or 'f16'")
         object.__setattr__(self, "_engine_dtype", v)
         self._engine = None
 
     def engine(self):
         if self._engine is None:
-            if self.engine_dtype == "bf16":
-                from ..engine_three_bf16 import EngineThreeBF16
-                self._engine = EngineThreeBF16(self)
+            if self.engine_dtype in ("bf16", "f16"):
+                from ..engine_three_bf16 import EngineThreeBF16, EngineThreeF16
+                self._engine = (EngineThreeF16 if self.engine_dtype == "f16" else EngineThreeBF16)(self)
             else:
                 from ..engine_three import EngineThree
                 self._engine = EngineThree(self)
@@ -423,16 +424,16 @@ class DLAPlanAWindowSeq(DLAPlanAWindowThree):
 
     @engine_dtype.setter
     def engine_dtype(self, v):
-        if v not in ("f32", "bf16"):
-            raise ValueError("engine_dtype must be 'f32' or 'bf16'")
+        if v not in ("f32", "bf16", "f16"):
+            raise ValueError("engine_dtype must be 'f32', 'bf16' or 'f16'")
         object.__setattr__(self, "_engine_dtype", v)
         self._engine = None
 
     def engine(self):
         if self._engine is None:
-            if self.engine_dtype == "bf16":
-                from ..engine_seq_bf16 import EngineSeqBF16
-                self._engine = EngineSeqBF16(self)
+            if self.engine_dtype in ("bf16", "f16"):
+                from ..engine_seq_bf16 import EngineSeqBF16, EngineSeqF16
+                self._engine = (EngineSeqF16 if self.engine_dtype == "f16" else EngineSeqBF16)(self)
             else:
                 from ..engine_seq import EngineSeq
                 self._engine = EngineSeq(self)

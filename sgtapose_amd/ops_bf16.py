@@ -14,6 +14,37 @@ DCN_MARGIN = None           # tests / tools: force the DCN window margin (6 or 1
 DEBUG_OM_SCALE = None       # tools: multiply the DCN sampling offsets (never set in the product)
 FORCE_NPF = None            # tools / tests: force the conv tile size (1: 256 positions, 2: 512)
 BF16 = torch.bfloat16
+F16 = torch.float16
+# The 16-bit data path exists in two element formats with the same layouts and kernels: bfloat16 (C ABI ``sgta_*_bf16``) and
+# IEEE half (``sgta_*_f16``: 11 significant bits instead of 8 -- an eighth of bf16's rounding error -- and a range of
+# +-65504, clamped on store).  Activations carry their format in their torch dtype; packed weights in ``.dtype``.
+_SUFFIX = {BF16: "bf16", F16: "f16"}
+_PACK_DTYPE = [BF16]
+
+
+class pack_dtype:
+    """Context manager: the element format the Packed* classes below convert weights to (an engine packs inside it)."""
+
+    def __init__(self, dtype):
+        assert dtype in _SUFFIX
+        self.dtype = dtype
+
+    def __enter__(self):
+        _PACK_DTYPE.append(self.dtype)
+
+    def __exit__(self, *exc):
+        _PACK_DTYPE.pop()
+
+
+def _to16(t, dtype):
+    return (t.clamp(-65504.0, 65504.0) if dtype == F16 else t).to(dtype)
+
+
+def _sfx(t):
+    try:
+        return _SUFFIX[t.dtype]
+    except KeyError:
+        raise _lib.SgtaHipError("16-bit data path: expected a bfloat16 or float16 tensor, got %s" % t.dtype)
 
 
 class ViewH:
@@ -55,10 +86,10 @@ class ViewH:
         return b.permute(0, 1, 4, 2, 3).reshape(self.N, self.C, self.H, self.W).float()
 
 
-def blocked_from_nchw(t, device=None):
-    """float [N, C, H, W] (C % 16 == 0) -> bf16 blocked [N, C/16, H, W, 16] (tests, boundary conversions)."""
+def blocked_from_nchw(t, device=None, dtype=BF16):
+    """float [N, C, H, W] (C % 16 == 0) -> 16-bit blocked [N, C/16, H, W, 16] (tests, boundary conversions)."""
     N, C, H, W = t.shape
-    out = t.reshape(N, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous().to(BF16)
+    out = _to16(t.reshape(N, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous(), dtype)
     return out.to(device) if device is not None else out
 
 
@@ -82,7 +113,8 @@ def _swizzle_rows(img, KC):
 class PackedConvBF16:
     """bf16 weights of one conv in the [cout tile][chunk][tap][TC][KC] LDS-image layout of sgta_conv_bf16, BN folded."""
 
-    def __init__(self, weight, bias=None, bn=None, stride=1, cout_pad_to=None, na=None):
+    def __init__(self, weight, bias=None, bn=None, stride=1, cout_pad_to=None, na=None, dtype=None):
+        self.dtype = dtype = _PACK_DTYPE[-1] if dtype is None else dtype
         w, b = fold_bn(weight.detach().float(), None if bias is None else bias.detach().float(), bn)
         co, ci, ks, _ = w.shape
         if cout_pad_to is not None and cout_pad_to > co:                 # e.g. the 27-channel offset / mask conv -> 32
@@ -104,11 +136,11 @@ class PackedConvBF16:
         wp = w.new_zeros(n_ct * self.TC, ci, taps)
         wp[:co] = w.reshape(co, ci, taps)
         img = wp.view(n_ct, self.TC, nch, self.kc, taps).permute(0, 2, 4, 1, 3).contiguous()    # [ct][chunk][tap][TC][KC]
-        self.wt = _swizzle_rows(img, self.kc).to(BF16).contiguous()
+        self.wt = _to16(_swizzle_rows(img, self.kc), dtype).contiguous()
         bb = b.new_zeros(n_ct * self.TC)
         bb[:co] = b
         self.bias = bb.float().contiguous()
-        self.w_ref = w.to(BF16)                   # tests: the rounded weights, [Cout, Cin, ks, ks]
+        self.w_ref = _to16(w, dtype)              # tests: the rounded weights, [Cout, Cin, ks, ks]
 
     def tile_npf(self, N, Ho, Wo):
         """32-position fragments per wave: 2 (512-position tiles) unless the launch would leave the chip's 256 CUs a short
@@ -152,7 +184,7 @@ class PackedConvBF16:
 def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_BLOCKED, nsig=0, cout=None):
     """out = act(conv(x) + bias [+ res]).  x: ViewH (bf16); out: ViewH (bf16 blocked / f32 NHWC) or a contiguous f32 NCHW
     tensor (out_mode = OUT_F32_NCHW, sigmoid on channels < nsig); res: ViewH bf16 at the output resolution."""
-    assert x.base.dtype == BF16 and x.C == pc.Cin
+    assert x.base.dtype == pc.dtype and x.C == pc.Cin
     Ho, Wo = (x.H - 1) // pc.stride + 1, (x.W - 1) // pc.stride + 1
     cout = pc.Cout if cout is None else cout
     assert x.blocked
@@ -160,13 +192,13 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_BLOCKED, nsig=0, 
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (x.N, cout, Ho, Wo)
         yptr, ldy = out.data_ptr(), 0
     else:
-        assert out.base.dtype == (BF16 if out_mode == OUT_BF16_BLOCKED else torch.float32)
+        assert out.base.dtype == (pc.dtype if out_mode == OUT_BF16_BLOCKED else torch.float32)
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, cout)
         yptr, ldy = (out.ptr, out.bs) if out_mode == OUT_BF16_BLOCKED else (out.ptr, out.ld)
         assert out.blocked == (out_mode == OUT_BF16_BLOCKED)
     rp, ldr = None, 0
     if res is not None:
-        assert res.base.dtype == BF16 and res.blocked and (res.N, res.H, res.W, res.C) == (x.N, Ho, Wo, cout)
+        assert res.base.dtype == pc.dtype and res.blocked and (res.N, res.H, res.W, res.C) == (x.N, Ho, Wo, cout)
         rp, ldr = res.ptr, res.bs
     meta = None
     if _lib.PROFILE is not None:
@@ -175,7 +207,7 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_BF16_BLOCKED, nsig=0, 
                 "exec_flops": pc.flops(M),
                 "bytes": 2.0 * (pc.Cin * x.N * x.H * x.W + pc.Cout * pc.Cin * pc.ks ** 2) + (2.0 if out_mode == 0 else 4.0) * cout * M}
     npf = pc.tile_npf(x.N, Ho, Wo)
-    _lib.call("sgta_conv_bf16", x.ptr, x.nbytes, x.bs, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
+    _lib.call("sgta_conv_" + _SUFFIX[pc.dtype], x.ptr, x.nbytes, x.bs, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
               rp, ldr, yptr, ldy, x.N, x.H, x.W, pc.Cin, cout, pc.ks, pc.stride, pc.kc, pc.na, npf,
               pc.tile_log_tw(x.N, Ho, Wo, npf), act, out_mode, nsig, _stream(), meta=meta)
     return out
@@ -185,10 +217,11 @@ class PackedHeadsBF16:
     """Weights of sgta_heads_bf16: ``pc1`` = PackedConvBF16 of the concatenated 3x3 convs (na = 4) and the block-diagonal 1x1
     weights of all heads as A fragments of the second product.  heads: [(w3x3, b3x3, w1x1, b1x1), ...] in output order."""
 
-    def __init__(self, heads):
+    def __init__(self, heads, dtype=None):
+        self.dtype = dtype = _PACK_DTYPE[-1] if dtype is None else dtype
         w1 = torch.cat([h[0].detach().float() for h in heads], 0)
         b1 = torch.cat([h[1].detach().float() for h in heads], 0)
-        self.pc1 = PackedConvBF16(w1, b1)
+        self.pc1 = PackedConvBF16(w1, b1, dtype=dtype)
         chid = w1.shape[0]
         self.rows = [h[2].shape[0] for h in heads]
         if self.pc1.na != 4 or chid % 128 or len(heads) > 4 or sum(self.rows) > 16:
@@ -211,15 +244,15 @@ class PackedHeadsBF16:
                 for t in range(2):
                     ch = 128 * ct + 32 * i + 8 * (2 * t + (j[None, :] >> 2)) + 4 * h[:, None] + (j[None, :] & 3)     # [64, 8]
                     frag[ct, i, t] = W2[m[:, None].expand(64, 8), ch]
-        self.w2 = frag.to(BF16).contiguous()
+        self.w2 = _to16(frag, dtype).contiguous()
         self.b2 = b2.contiguous()
-        self.w2_ref = W2[:16].to(BF16)            # tests: [16, Chid] rounded
+        self.w2_ref = _to16(W2[:16], dtype)       # tests: [16, Chid] rounded
         self.Chid = chid
 
 
 def heads_fused(x, pk, outs, nsig=0):
     """outs[i] (f32 NCHW [N, rows_i, H, W]) = head i of the fused head kernel on x (ViewH bf16)."""
-    assert x.blocked and x.base.dtype == BF16 and x.C == pk.pc1.Cin and len(outs) == len(pk.rows)
+    assert x.blocked and x.base.dtype == pk.dtype and x.C == pk.pc1.Cin and len(outs) == len(pk.rows)
     for o, n in zip(outs, pk.rows):
         assert o.dtype == torch.float32 and o.is_contiguous() and tuple(o.shape) == (x.N, n, x.H, x.W)
     meta = None
@@ -231,7 +264,7 @@ def heads_fused(x, pk, outs, nsig=0):
     npf = HEADS_NPF if FORCE_NPF is None else FORCE_NPF
     ptrs = [o.data_ptr() for o in outs] + [None] * (4 - len(outs))
     rows = list(pk.rows) + [0] * (4 - len(outs))
-    _lib.call("sgta_heads_bf16", x.ptr, x.nbytes, x.bs, pk.pc1.wt.data_ptr(), pk.pc1.wt.numel() * 2, pk.pc1.bias.data_ptr(),
+    _lib.call("sgta_heads_" + _SUFFIX[pk.dtype], x.ptr, x.nbytes, x.bs, pk.pc1.wt.data_ptr(), pk.pc1.wt.numel() * 2, pk.pc1.bias.data_ptr(),
               pk.w2.data_ptr(), pk.b2.data_ptr(), *ptrs, *rows, x.N, x.H, x.W, pk.pc1.Cin, pk.Chid, npf,
               pk.pc1.tile_log_tw(x.N, x.H, x.W, npf), nsig, _stream(), meta=meta)
     return outs
@@ -279,7 +312,7 @@ class PackedDCNBF16:
 
 def dcn_v2(x, om, pc, out, act=ACT_RELU):
     """x: ViewH bf16; om: ViewH float32 (>= 27 channels: the raw offset / mask conv output); out: ViewH bf16."""
-    assert x.base.dtype == BF16 and om.base.dtype == torch.float32 and out.base.dtype == BF16
+    assert x.base.dtype in _SUFFIX and om.base.dtype == torch.float32 and out.base.dtype == x.base.dtype
     assert x.C == pc.Cin and out.C == pc.Cout and om.C >= 27 and x.blocked and out.blocked and not om.blocked
     assert (om.N, om.H, om.W) == (x.N, x.H, x.W) == (out.N, out.H, out.W)
     if DEBUG_OM_SCALE is not None:                 # tools only: scale the sampling offsets (how much of the time is the far-sample path?)
@@ -291,7 +324,7 @@ def dcn_v2(x, om, pc, out, act=ACT_RELU):
                 "bytes": 2.0 * M * (pc.Cin + pc.Cout) + 4.0 * 27 * M + 2.0 * pc.Cout * pc.Cin * 9}
     # deep levels (small maps) sample far from the output pixel: wide window + patch slots (dcn_bf16.hip); speed only
     margin = DCN_MARGIN if DCN_MARGIN is not None else (10 if x.H * x.W <= DCN_WIDE_MAX_HW else 6)
-    _lib.call("sgta_dcnv2_fwd_bf16", x.ptr, x.bs, om.ptr, om.ld, pc.wt.data_ptr(), pc.wt.numel() * 2,
+    _lib.call("sgta_dcnv2_fwd_" + _sfx(x.base), x.ptr, x.bs, om.ptr, om.ld, pc.wt.data_ptr(), pc.wt.numel() * 2,
               pc.bias.data_ptr(), out.ptr, out.bs, x.N, x.H, x.W, pc.Cin, pc.Cout, pc.na,
               pc.tile_log_tw(x.N, x.H, x.W, margin), margin, act, _stream(), meta=meta)
     return out
@@ -302,13 +335,13 @@ def stem(img, hm, pc16, out):
     pc16: ops.PackedC16 of the two stems (fp32 weights, f32 MFMA: the inputs are fp32 at the boundary)."""
     assert img.dtype == torch.float32 and hm.dtype == torch.float32 and img.is_contiguous() and hm.is_contiguous()
     B, _, H, W = img.shape
-    assert out.base.dtype == BF16 and out.blocked and (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
+    assert out.base.dtype in _SUFFIX and out.blocked and (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
     meta = None
     if _lib.PROFILE is not None:
         M = B * H * W
         meta = {"kernel": "stem_c16_kernel<bf16>", "flops": pc16.flops(M), "exec_flops": pc16.flops(M) * 200.0 / 196.0,
                 "bytes": M * (16.0 + 32.0)}
-    _lib.call("sgta_stem_bf16", img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pc16.wt.data_ptr(),
+    _lib.call("sgta_stem_" + _sfx(out.base), img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pc16.wt.data_ptr(),
               pc16.bias.data_ptr(), out.ptr, 16, B, H, W, _stream(), meta=meta)
     return out
 
@@ -320,7 +353,8 @@ class PackedStemL0BF16:
     """bf16 A fragments of sgta_stem_level0_bf16: the two 7x7 stems (image 3 -> 16, prior map 1 -> 16) and level0
     (3x3, 16 -> 16), BatchNorm folded.  ``w_img_ref`` / ``w_hm_ref`` / ``w_l0_ref`` are the rounded weights (tests)."""
 
-    def __init__(self, w_img, bn_img, w_hm, bn_hm, w_l0, bn_l0):
+    def __init__(self, w_img, bn_img, w_hm, bn_hm, w_l0, bn_l0, dtype=None):
+        self.dtype = dtype = _PACK_DTYPE[-1] if dtype is None else dtype
         wi, bi = fold_bn(w_img.detach().float(), None, bn_img)
         wh, bh = fold_bn(w_hm.detach().float(), None, bn_hm)
         wl, bl = fold_bn(w_l0.detach().float(), None, bn_l0)
@@ -346,11 +380,11 @@ class PackedStemL0BF16:
             t = 2 * s + (g >> 1)
             for j in range(8):
                 wf[s, :, j] = wl9[cout, 8 * (g & 1) + j, t]
-        self.w_stem = ws.to(BF16).contiguous()
-        self.w_l0 = wf.to(BF16).contiguous()
+        self.w_stem = _to16(ws, dtype).contiguous()
+        self.w_l0 = _to16(wf, dtype).contiguous()
         self.b_stem = torch.cat([bi, bh]).float().contiguous()
         self.b_l0 = bl.float().contiguous()
-        self.w_img_ref, self.w_hm_ref, self.w_l0_ref = wi.to(BF16), wh.to(BF16), wl.to(BF16)
+        self.w_img_ref, self.w_hm_ref, self.w_l0_ref = _to16(wi, dtype), _to16(wh, dtype), _to16(wl, dtype)
         self.b_img_ref, self.b_hm_ref = bi, bh
 
     @staticmethod
@@ -363,20 +397,20 @@ def stem_level0(img, hm, pk, out):
     NCHW tensors at the API boundary."""
     assert img.dtype == torch.float32 and hm.dtype == torch.float32 and img.is_contiguous() and hm.is_contiguous()
     B, _, H, W = img.shape
-    assert out.base.dtype == BF16 and out.blocked and (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
+    assert out.base.dtype == pk.dtype and out.blocked and (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
     meta = None
     if _lib.PROFILE is not None:
         M = B * H * W
         meta = {"kernel": "stem_l0_bf16_kernel", "flops": pk.flops(M), "exec_flops": 2.0 * M * 16 * (14 * 32 + 5 * 32),
                 "bytes": M * (16.0 + 32.0)}
-    _lib.call("sgta_stem_level0_bf16", img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pk.w_stem.data_ptr(),
+    _lib.call("sgta_stem_level0_" + _SUFFIX[pk.dtype], img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pk.w_stem.data_ptr(),
               pk.b_stem.data_ptr(), pk.w_l0.data_ptr(), pk.b_l0.data_ptr(), out.ptr, out.bs, B, H, W, _stream(), meta=meta)
     return out
 
 
 def maxpool2(x, out):
-    assert x.base.dtype == BF16 and out.base.dtype == BF16 and out.C == x.C
-    _lib.call("sgta_maxpool2_bf16", x.ptr, x.bs, out.ptr, out.bs, x.N, x.C, x.H, x.W, _stream())
+    assert x.base.dtype in _SUFFIX and out.base.dtype == x.base.dtype and out.C == x.C
+    _lib.call("sgta_maxpool2_" + _sfx(x.base), x.ptr, x.bs, out.ptr, out.bs, x.N, x.C, x.H, x.W, _stream())
     return out
 
 
@@ -387,7 +421,8 @@ def pack_up_weight(w):
 
 def upsample_add(x, w_kkc, skip, out, f):
     sp, lds = (skip.ptr, skip.bs) if skip is not None else (None, 0)
-    _lib.call("sgta_upsample_add_bf16", x.ptr, x.bs, w_kkc.data_ptr(), sp, lds, out.ptr, out.bs, x.N, x.C, x.H, x.W, f,
+    assert out.base.dtype == x.base.dtype and (skip is None or skip.base.dtype == x.base.dtype)
+    _lib.call("sgta_upsample_add_" + _sfx(x.base), x.ptr, x.bs, w_kkc.data_ptr(), sp, lds, out.ptr, out.bs, x.N, x.C, x.H, x.W, f,
               _stream())
     return out
 
@@ -395,7 +430,7 @@ def upsample_add(x, w_kkc, skip, out, f):
 def window_gather(feats, fid, tok, col0=0):
     B, n = fid.shape
     assert tok.dtype == torch.float32 and tok.stride(-1) == 1
-    _lib.call("sgta_window_gather_bf16", feats.ptr, feats.bs, fid.data_ptr(), tok.data_ptr(), B, feats.C, feats.H,
+    _lib.call("sgta_window_gather_" + _sfx(feats.base), feats.ptr, feats.bs, fid.data_ptr(), tok.data_ptr(), B, feats.C, feats.H,
               feats.W, n, tok.stride(0), col0, _stream())
     return tok
 
@@ -403,6 +438,6 @@ def window_gather(feats, fid, tok, col0=0):
 def window_scatter(tok, fid, win, feats):
     B, n = fid.shape
     assert tok.dtype == torch.float32 and tok.stride(-1) == 1 and tok.shape[-1] == feats.C
-    _lib.call("sgta_window_scatter_bf16", tok.data_ptr(), tok.stride(0), fid.data_ptr(), win.data_ptr(), feats.ptr,
+    _lib.call("sgta_window_scatter_" + _sfx(feats.base), tok.data_ptr(), tok.stride(0), fid.data_ptr(), win.data_ptr(), feats.ptr,
               feats.bs, B, feats.C, feats.H, feats.W, n, _stream())
     return feats

@@ -1,0 +1,321 @@
+"""GPU (-m gpu): the IEEE-half twin of the 16-bit data path (C ABI ``sgta_*_f16``, ``model.engine_dtype = "f16"``).
+
+Operator level: each kernel against torch fp32 ON THE fp16-ROUNDED inputs and weights, so the only differences are the
+accumulation order and the final rounding to fp16 (relative 2^-11): |got - ref| <= 1.5e-3 |ref| + 4e-4 max|ref|.
+Network level: the f16 engine against the fp32 CPU oracle with the stated f16 tolerance (F16_LOGIT_TOL below, an eighth
+of the bf16 path's), and key-points on the peaked weight set.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from util import ARGS, golden_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HF = torch.float16
+
+
+@pytest.fixture(scope="module")
+def bops():
+    from sgtapose_amd import _lib, ops_bf16
+    _lib.load()
+    assert _lib.call("sgta_check_device") == 0
+    return ops_bf16
+
+
+def to_blk(t_nchw):
+    N, C, H, W = t_nchw.shape
+    return t_nchw.reshape(N, C // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous().to(HF).to(DEV)
+
+
+def nchw(t_blk):
+    N, Cb, H, W, _ = t_blk.shape
+    return t_blk.float().cpu().permute(0, 1, 4, 2, 3).reshape(N, Cb * 16, H, W).contiguous()
+
+
+def blocked(N, C, H, W, fill=None):
+    t = torch.empty(N, C // 16, H, W, 16, dtype=HF, device=DEV)
+    return t.zero_() if fill is None else t.fill_(fill)
+
+
+def close(got, ref, rtol=1.5e-3, atol_rel=4e-4):
+    tol = rtol * ref.abs() + atol_rel * float(ref.abs().max())
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), "max err %.4g (ref max %.4g), %d bad" % (
+        float((got - ref).abs().max()), float(ref.abs().max()), int(bad.sum()))
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,ks,stride,act,res", [
+    (2, 32, 64, 9, 13, 1, 1, 0, False), (3, 448, 128, 6, 10, 1, 1, 1, False), (2, 16, 16, 20, 36, 3, 1, 1, False),
+    (1, 64, 64, 17, 23, 3, 1, 1, True), (3, 128, 256, 8, 12, 3, 1, 1, True), (2, 16, 32, 16, 24, 3, 2, 1, False),
+    (5, 256, 512, 6, 8, 3, 2, 1, False), (4, 512, 512, 15, 20, 3, 1, 1, True), (1, 64, 768, 24, 40, 3, 1, 1, False),
+    (2, 64, 32, 12, 70, 3, 1, 0, False),
+])
+def test_conv_f16(bops, N, cin, cout, H, W, ks, stride, act, res):
+    g = torch.Generator().manual_seed(N * 1000 + cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(HF).float()
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * (1.5 / (cin * ks * ks) ** 0.5))
+    b = torch.randn(cout, generator=g) * 0.2
+    pc = bops.PackedConvBF16(w.to(DEV), b.to(DEV), None, stride=stride, dtype=HF)
+    assert pc.wt.dtype == HF
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, cout, Ho, Wo, generator=g).to(HF).float() if res else None
+    ref = F.conv2d(x, pc.w_ref.float().cpu(), b, stride=stride, padding=ks // 2)
+    if res:
+        ref = ref + r
+    if act:
+        ref = F.relu(ref)
+    out = blocked(N, cout, Ho, Wo, 7.0)
+    bops.conv(bops.ViewH(to_blk(x)), pc, bops.ViewH(out), act, res=bops.ViewH(to_blk(r)) if res else None)
+    close(nchw(out), ref)
+
+
+def test_conv_f16_saturates_instead_of_overflowing(bops):
+    """A result beyond the fp16 range is stored as +-65504, never as infinity."""
+    x = torch.full((1, 16, 8, 8), 200.0)
+    w = torch.full((16, 16, 3, 3), 4.0)
+    w[8:] = -4.0
+    pc = bops.PackedConvBF16(w.to(DEV), None, None, dtype=HF)
+    out = blocked(1, 16, 8, 8)
+    bops.conv(bops.ViewH(to_blk(x)), pc, bops.ViewH(out), 0)
+    o = nchw(out)
+    assert bool(torch.isfinite(o).all()) and float(o[:, :8, 3, 3].min()) == 65504.0 and float(o[:, 8:, 3, 3].max()) == -65504.0
+
+
+def test_conv_f16_channel_slices_and_fp32_outputs(bops):
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 14, 22
+    big = torch.randn(N, 96, H, W, generator=g).to(HF).float()
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.1
+    pc = bops.PackedConvBF16(w.to(DEV), b.to(DEV), dtype=HF)
+    xin = bops.ViewH(to_blk(big)).slice(32, 32)
+    outbuf = blocked(N, 160, H, W)
+    bops.conv(xin, pc, bops.ViewH(outbuf).slice(64, 64), 1)
+    close(nchw(outbuf[:, 4:8]), F.relu(F.conv2d(big[:, 32:64], pc.w_ref.float().cpu(), b, padding=1)))
+    assert float(outbuf[:, :4].abs().max()) == 0 and float(outbuf[:, 8:].abs().max()) == 0
+    w27 = torch.randn(27, 32, 3, 3, generator=g) * 0.1
+    b27 = torch.randn(27, generator=g) * 0.3
+    pco = bops.PackedConvBF16(w27.to(DEV), b27.to(DEV), cout_pad_to=32, dtype=HF)
+    om = torch.full((N, H, W, 32), 3.0, dtype=torch.float32, device=DEV)
+    bops.conv(xin, pco, bops.ViewH(om), 0, out_mode=bops.OUT_F32_NHWC)
+    refo = F.conv2d(big[:, 32:64], pco.w_ref.float().cpu()[:27], b27, padding=1)
+    got = om.cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got[:, :27], refo, atol=1e-4, rtol=1e-4) and float(got[:, 27:].abs().max()) == 0
+    with pytest.raises(AssertionError):                       # a bf16 tensor into an f16-packed conv is refused on the host
+        bops.conv(bops.ViewH(to_blk(big).to(torch.bfloat16)).slice(32, 32), pc, bops.ViewH(outbuf).slice(64, 64), 1)
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,off_scale", [(2, 64, 64, 17, 23, 1.5), (1, 128, 128, 15, 20, 4.0),
+                                                      (1, 512, 256, 15, 20, 2.0), (2, 256, 64, 30, 40, 8.0),
+                                                      (1, 64, 64, 120, 160, 3.0)])
+def test_dcn_f16_matches_oracle(bops, N, cin, cout, H, W, off_scale):
+    """sgta_dcnv2_fwd_f16 against oracle.dcn_v2_im2col + GEMM on the fp16-rounded x / weights with the same fp32 offsets
+    and mask logits, both window margins (LDS gathers, patch slots, the global-memory path)."""
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g).to(HF).float()
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (1.5 / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    om = torch.randn(N, 27, H, W, generator=g) * off_scale
+    pc = bops.PackedDCNBF16(w.to(DEV), b.to(DEV))
+    col = oracle.dcn_v2_im2col(x, om[:, :18], torch.sigmoid(om[:, 18:27]))
+    ref = torch.matmul(pc.w_ref.float().cpu().reshape(cout, cin * 9), col.reshape(N, cin * 9, H * W)).view(N, cout, H, W)
+    ref = F.relu(ref + b.view(1, -1, 1, 1))
+    om32 = torch.zeros(N, H, W, 32, device=DEV)
+    om32[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
+    for margin in (6, 10):
+        out = blocked(N, cout, H, W, 5.0)
+        bops.DCN_MARGIN = margin
+        try:
+            bops.dcn_v2(bops.ViewH(to_blk(x)), bops.ViewH(om32), pc, bops.ViewH(out), 1)
+        finally:
+            bops.DCN_MARGIN = None
+        # corner weights and the blended sample are rounded to fp16 (three packed fma roundings) before the product
+        close(nchw(out), ref, rtol=4e-3, atol_rel=2.5e-3)
+
+
+def test_elementwise_f16(bops):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 32, 10, 14, generator=g).to(HF).float()
+    out = blocked(3, 64, 5, 7)
+    bops.maxpool2(bops.ViewH(to_blk(x)), bops.ViewH(out).slice(16, 32))
+    assert torch.equal(nchw(out[:, 1:3]), F.max_pool2d(x, 2))
+    assert float(out[:, :1].abs().max()) == 0 and float(out[:, 3:].abs().max()) == 0
+    for f in (2, 4):
+        w = torch.randn(32, 1, 2 * f, 2 * f, generator=g)
+        skip = torch.randn(3, 32, 10 * f, 14 * f, generator=g).to(HF).float()
+        ref = F.conv_transpose2d(x, w, stride=f, padding=f // 2, groups=32) + skip
+        o = blocked(3, 32, 10 * f, 14 * f)
+        bops.upsample_add(bops.ViewH(to_blk(x)), bops.pack_up_weight(w.to(DEV)), bops.ViewH(to_blk(skip)), bops.ViewH(o), f)
+        close(nchw(o), ref, rtol=1e-3, atol_rel=3e-4)
+    B, C, H, W, n = 3, 32, 10, 14, 20
+    fid = torch.randint(0, H * W, (B, n), generator=g)
+    fid[0, 5] = fid[0, 2]
+    win = torch.ones(B, n, dtype=torch.uint8)
+    for b in range(B):
+        for t_ in range(n):
+            win[b, t_] = int(not bool((fid[b, t_ + 1:] == fid[b, t_]).any()))
+    feats = bops.ViewH(to_blk(x))
+    tok = torch.zeros(B * n, 40, device=DEV)
+    bops.window_gather(feats, fid.to(DEV), tok, col0=8)
+    ref = torch.gather(x.reshape(B, C, -1), 2, fid.view(B, 1, n).expand(B, C, n)).permute(0, 2, 1).reshape(B * n, C)
+    assert torch.equal(tok[:, 8:].cpu(), ref) and float(tok[:, :8].abs().max()) == 0
+    new = torch.randn(B * n, C, generator=g)
+    bops.window_scatter(new.to(DEV), fid.to(DEV), win.to(DEV), feats)
+    want = x.reshape(B, C, -1).clone()
+    for b in range(B):
+        for t in range(n):
+            want[b, :, fid[b, t]] = new[b * n + t].to(HF).float()
+    assert torch.equal(nchw(feats.base).reshape(B, C, -1), want)
+
+
+def _bn(g):
+    return (torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1,
+            torch.randn(16, generator=g) * 0.1, torch.rand(16, generator=g) + 0.5)
+
+
+def test_stem_f16(bops):
+    from sgtapose_amd.ops import PackedC16
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 2, 24, 40
+    img = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    hm = torch.rand(B, 1, H, W, generator=g)
+    wi, wh = torch.randn(16, 3, 7, 7, generator=g) * 0.1, torch.randn(16, 1, 7, 7, generator=g) * 0.15
+    bi, bh = _bn(g), _bn(g)
+    pc = PackedC16(wi.to(DEV), tuple(t.to(DEV) for t in bi), wh.to(DEV), tuple(t.to(DEV) for t in bh))
+    out = blocked(B, 16, H, W)
+    bops.stem(img.to(DEV), hm.to(DEV), pc, bops.ViewH(out))
+    ref = (F.relu(F.batch_norm(F.conv2d(img, wi, padding=3), bi[2], bi[3], bi[0], bi[1], False, 0.0, 1e-5)) +
+           F.relu(F.batch_norm(F.conv2d(hm, wh, padding=3), bh[2], bh[3], bh[0], bh[1], False, 0.0, 1e-5)))
+    close(nchw(out), ref, rtol=1e-3, atol_rel=3e-4)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 24, 40), (1, 48, 136), (1, 37, 68)])
+def test_stem_level0_fused_f16(bops, B, H, W):
+    g = torch.Generator().manual_seed(H + W)
+    img = (torch.rand(B, 3, H, W, generator=g) * 4 - 2)
+    hm = torch.rand(B, 1, H, W, generator=g)
+    wi, wh = torch.randn(16, 3, 7, 7, generator=g) * 0.1, torch.randn(16, 1, 7, 7, generator=g) * 0.15
+    wl = torch.randn(16, 16, 3, 3, generator=g) * 0.12
+    bi, bh, bl = _bn(g), _bn(g), _bn(g)
+    dv = lambda t: tuple(x.to(DEV) for x in t)                                               # noqa: E731
+    pk = bops.PackedStemL0BF16(wi.to(DEV), dv(bi), wh.to(DEV), dv(bh), wl.to(DEV), dv(bl), dtype=HF)
+    out = blocked(B, 16, H, W, 9.0)
+    bops.stem_level0(img.to(DEV), hm.to(DEV), pk, bops.ViewH(out))
+    r = lambda t: t.to(HF).float()                                                           # noqa: E731
+    s = (F.relu(F.conv2d(r(img), pk.w_img_ref.float().cpu(), pk.b_img_ref.cpu(), padding=3)) +
+         F.relu(F.conv2d(r(hm), pk.w_hm_ref.float().cpu(), pk.b_hm_ref.cpu(), padding=3)))
+    ref = F.relu(F.conv2d(r(s), pk.w_l0_ref.float().cpu(), pk.b_l0.cpu(), padding=1))
+    close(nchw(out), ref, rtol=1.5e-3, atol_rel=6e-4)
+
+
+@pytest.mark.parametrize("N,H,W,npf", [(2, 14, 22, 2), (1, 30, 40, 1)])
+def test_heads_fused_f16(bops, N, H, W, npf):
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, 64, H, W, generator=g).to(HF).float()
+    heads, ref = [], []
+    for n in (7, 2, 2):
+        w3 = torch.randn(256, 64, 3, 3, generator=g) * 0.06
+        b3 = torch.randn(256, generator=g) * 0.1
+        w1 = torch.randn(n, 256, 1, 1, generator=g) * 0.1
+        b1 = torch.randn(n, generator=g)
+        heads.append(tuple(t.to(DEV) for t in (w3, b3, w1, b1)))
+        hid = F.relu(F.conv2d(x, w3.to(HF).float(), b3, padding=1)).to(HF).float()
+        ref.append(F.conv2d(hid, w1.to(HF).float(), b1))
+    ref[0] = torch.sigmoid(ref[0])
+    pk = bops.PackedHeadsBF16(heads, dtype=HF)
+    outs = [torch.full((N, n, H, W), 5.0, device=DEV) for n in (7, 2, 2)]
+    bops.FORCE_NPF = npf
+    try:
+        bops.heads_fused(bops.ViewH(to_blk(x)), pk, outs, nsig=7)
+    finally:
+        bops.FORCE_NPF = None
+    for o, r in zip(outs, ref):
+        assert torch.allclose(o.cpu(), r, atol=6e-4, rtol=4e-4), float((o.cpu() - r).abs().max())
+
+
+# ---- network level ---------------------------------------------------------------------------------------------------
+F16_LOGIT_TOL = 8e-3        # max |logit_f16 - logit_fp32 oracle| on hm / reg / tracking (bf16 path: 6e-2)
+F16_LOGIT_MEAN_TOL = 1e-3   # mean (bf16 path: 8e-3)
+
+
+def _f16_model(peaked=False):
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
+    m.load_state_dict(golden_state_dict(0, peaked=peaked), strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "f16"
+    return m
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(2, 128, 160, 11), (1, 480, 640, 321), (3, 96, 224, 13)])
+def test_f16_network_matches_fp32_oracle(B, H, W, seed):
+    from sgtapose_amd.engine_bf16 import EngineF16
+    from sgtapose_amd.synthetic import make_inputs
+    m = _f16_model()
+    assert isinstance(m.engine(), EngineF16)
+    inp = make_inputs(B, H, W, seed=seed)
+    out = m(*[inp[k].to(DEV) for k in ARGS])[-1]
+    ref = oracle.plan_a_window_forward(golden_state_dict(0), *[inp[k] for k in ARGS])
+    for k in ("hm", "reg", "tracking"):
+        assert out[k].dtype == torch.float32 and out[k].shape == ref[k].shape
+        d = (out[k].cpu() - ref[k]).abs()
+        print("f16 vs fp32 oracle %-8s max %.5f mean %.6f (ref std %.3f)" % (k, float(d.max()), float(d.mean()), float(ref[k].std())))
+        assert float(d.max()) <= F16_LOGIT_TOL and float(d.mean()) <= F16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
+
+
+def test_f16_temporal_window_and_three_frame_models_match_fp32_oracle():
+    from sgtapose_amd.engine_seq_bf16 import EngineSeqF16
+    from sgtapose_amd.engine_three_bf16 import EngineThreeF16
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from sgtapose_amd.synthetic import SEQ_ARGS, THREE_ARGS, fill_state_dict_, make_inputs_seq, make_inputs_three
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    m = create_model("dlapawdT_34", heads, default_head_conv(heads), default_opt(seq_len=4))
+    sd = fill_state_dict_({k: v.clone() for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "f16"
+    assert isinstance(m.engine(), EngineSeqF16)
+    inp = make_inputs_seq(2, 128, 160, T=4, seed=77)
+    mv = lambda v: [u.to(DEV) for u in v] if isinstance(v, list) else v.to(DEV)      # noqa: E731
+    out = m(*[mv(inp[k]) for k in SEQ_ARGS])[-1]
+    ref = oracle.plan_a_window_seq_forward(sd, *[inp[k] for k in SEQ_ARGS])
+    for k in out:
+        d = (out[k].cpu() - ref[k]).abs()
+        print("f16 T=4 vs fp32 oracle %-8s max %.5f mean %.6f" % (k, float(d.max()), float(d.mean())))
+        assert float(d.max()) <= F16_LOGIT_TOL and float(d.mean()) <= F16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
+    m3 = create_model("dlapawd3_34", heads, default_head_conv(heads), default_opt())
+    sd3 = fill_state_dict_({k: v.clone() for k, v in m3.state_dict().items()}, 4)
+    m3.load_state_dict(sd3, strict=True)
+    m3 = m3.to(DEV).eval()
+    m3.engine_dtype = "f16"
+    assert isinstance(m3.engine(), EngineThreeF16)
+    inp3 = make_inputs_three(2, 128, 160, seed=21)
+    out3 = m3(*[inp3[k].to(DEV) for k in THREE_ARGS])[-1]
+    ref3 = oracle.plan_a_window_three_forward(sd3, *[inp3[k] for k in THREE_ARGS])
+    for k in ("hm", "reg", "wh", "tracking"):
+        d = (out3[k].cpu() - ref3[k]).abs()
+        print("f16 three-frame %-8s max %.5f mean %.6f" % (k, float(d.max()), float(d.mean())))
+        assert float(d.max()) <= F16_LOGIT_TOL and float(d.mean()) <= F16_LOGIT_MEAN_TOL, (k, float(d.max()), float(d.mean()))
+
+
+def test_f16_step_is_deterministic_across_streams():
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    det = BatchedDetector(_f16_model())
+    inp = make_inputs(6, 128, 160, seed=5)
+    dev_in = [inp[k].to(DEV) for k in ARGS]
+    first = None
+    for i in range(8):
+        out, dets = det.process_device(*dev_in, static=True)
+        cur = {k: v.clone() for k, v in out.items()}
+        cur["kp"] = dets["kp"].clone()
+        if first is None:
+            first = cur
+        else:
+            for k in first:
+                assert torch.equal(first[k], cur[k]), (i, k)
+    torch.cuda.synchronize()
