@@ -177,11 +177,18 @@ def _median(v):
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
-def cpu_baseline(sd, inp, hip_out, hip_dets, budget_b8_s=60.0):
+# parity bars per compute dtype: fp32 = north_star's 1e-3 on heat-maps / key-points; the 16-bit paths = their STATED
+# tolerances on the logits (tests/test_bf16_parity.py, tests/test_f16_parity.py) -- a 16-bit run is never held to, or
+# reported against, the fp32 bar
+PARITY_BARS = {"f32": {"max_abs": 1e-3, "text": "1e-3 abs on hm / reg / tracking (north_star)"},
+               "f16": {"max_abs": 1.2e-2, "text": "stated f16 tolerance: 1.2e-2 abs on reg / tracking and on the hm logits"},
+               "bf16": {"max_abs": 6e-2, "text": "stated bf16 tolerance: 6e-2 abs on reg / tracking and on the hm logits"}}
+
+
+def cpu_reference(sd, inp, budget_b8_s=40.0):
     """The CPU oracle (kind 'port') timed on frame pairs OF THE BENCHED BATCH, all host threads: B=1 (median of 5 after
     2 warm-ups, five different samples) and B=8 (median of up to 5 after 1-2 warm-ups, bounded by ``budget_b8_s``).
-    The B=1 outputs double as the parity reference for the same samples of the HIP batch (``parity``)."""
-    import numpy as np
+    -> (cpu_baseline record, {sample index: (oracle output, oracle dets)}): the B=1 outputs are the parity reference."""
     import oracle
     B = inp["x"].shape[0]
     H, W = inp["x"].shape[2:]
@@ -217,15 +224,25 @@ def cpu_baseline(sd, inp, hip_out, hip_dets, budget_b8_s=60.0):
                 continue
             t8.append(dt)
         res["b8"] = {"value": round(8.0 / _median(t8), 4), "unit": "frame-pairs/s", "runs": len(t8), "warmups": warm,
-                     "sample": "B=8: samples 0..7 of the benched batch in one oracle call, median of %d runs" % len(t8)}
-    # ---- parity of the benched batch: the same samples through the HIP path (they ran at the full batch size) ----
-    err = {k: 0.0 for k in ("hm", "reg", "tracking")}
+                     "sample": "B=8: samples 0..7 of the benched batch in one oracle call, median of %d runs after %d warm-up(s) "
+                               "(bounded by a %.0f s budget)" % (len(t8), warm, budget_b8_s)}
+        res["sample"] += "; B=8: %d timed runs after %d warm-up(s)" % (len(t8), warm)
+    return res, refs
+
+
+def batch_parity(refs, hip_out, hip_dets, dtype):
+    """The samples in ``refs`` (oracle outputs) against the same samples of the HIP batch (they ran at the full batch size)."""
+    import numpy as np
+    bar = PARITY_BARS[dtype]
+    err = {k: 0.0 for k in ("hm", "hm_logit", "reg", "tracking")}
     found_ref = found_same = int_same = 0
     l2 = 0.0
     hip_kp = hip_dets["kp"]
     for i, (o, d) in refs.items():
-        for k in err:
+        for k in ("hm", "reg", "tracking"):
             err[k] = max(err[k], float((hip_out[k][i:i + 1].cpu() - o[k]).abs().max()))
+        lg = lambda t: torch.logit(t.double().clamp(1e-12, 1 - 1e-12))      # noqa: E731
+        err["hm_logit"] = max(err["hm_logit"], float((lg(hip_out["hm"][i:i + 1].cpu()) - lg(o["hm"])).abs().max()))
         kp_ref = np.concatenate([d["cts_wreg"][0].reshape(7, 2), d["scores"][0].reshape(7, 1)], 1)
         kp_hip = hip_kp[i].cpu().numpy().astype(np.float64)
         f = kp_ref[:, 2] >= 0
@@ -235,43 +252,54 @@ def cpu_baseline(sd, inp, hip_out, hip_dets, budget_b8_s=60.0):
                         np.array_equal(hip_dets["ys"][i].cpu().numpy(), d["ys"][0]))
         if f.any():
             l2 = max(l2, float(np.sqrt(((kp_hip[f, :2] - kp_ref[f, :2]) ** 2).sum(1)).max()))
-    res["parity"] = {"samples_of_benched_batch": sorted(refs), "hm_max_abs": err["hm"], "reg_max_abs": err["reg"],
-                     "tracking_max_abs": err["tracking"], "keypoints_found_ref": found_ref,
-                     "found_masks_identical": found_same == len(refs),
-                     "integer_peaks_identical": int_same == len(refs), "keypoint_l2_max_px": l2,
-                     "bar": "1e-3 abs (north_star); HIP ran these samples inside the full benched batch"}
-    return res, refs
+    worst = max(err["hm"] if dtype == "f32" else err["hm_logit"], err["reg"], err["tracking"])
+    return {"samples_of_benched_batch": sorted(refs), "hm_max_abs": err["hm"], "hm_logit_max_abs": err["hm_logit"],
+            "reg_max_abs": err["reg"], "tracking_max_abs": err["tracking"], "keypoints_found_ref": found_ref,
+            "found_masks_identical": found_same == len(refs),
+            "integer_peaks_identical": int_same == len(refs), "keypoint_l2_max_px": l2,
+            "bar": bar["text"] + "; HIP ran these samples inside the full benched batch",
+            "within_bar": bool(worst <= bar["max_abs"])}
 
 
-def peaked_parity(dev, inp, picks, dtype):
-    """Key-point parity with the second weight set (peaked heat-maps): the benched inputs through
-    a model whose 'hm' head emits isolated peaks, HIP at the full batch size vs the oracle on ``picks``; then both
-    decode dictionaries through post-process -> final_kps."""
-    import numpy as np
+def peaked_reference(inp, picks):
+    """Oracle outputs of ``picks`` with the second weight set (peaked heat-maps)."""
     import oracle
+    from util import golden_state_dict
+    sd = golden_state_dict(0, peaked=True)
+    return {i: oracle.process_reference(sd, *[inp[k][i:i + 1] for k in ARGS]) for i in picks}
+
+
+def peaked_parity(dev, inp, prefs, dtype):
+    """Key-point parity with the second weight set: the benched inputs through a model whose 'hm' head emits isolated
+    peaks, HIP at the full batch size vs the oracle outputs ``prefs``.  Per reference-found key-point: same integer peak?
+    sub-pixel distance of (x + reg_x, y + reg_y)?"""
+    import numpy as np
     from sgtapose_amd.detector import BatchedDetector
     from sgtapose_amd.synthetic import PEAKED_HM_BIAS, PEAKED_HM_GAIN
-    model, sd = build_model(dev, peaked=True)
-    if dtype == "bf16":
-        model.engine_dtype = "bf16"
+    model, _ = build_model(dev, peaked=True)
+    model.engine_dtype = dtype
     det = BatchedDetector(model)
     out, dets = det.process_device(*[inp[k].to(dev) for k in ARGS])
     kp = det.keypoints(dets).cpu().numpy().astype(np.float64)
-    found = same_int = n = 0
+    xs, ys, sc = dets["xs"].cpu().numpy(), dets["ys"].cpu().numpy(), dets["scores"].cpu().numpy()
+    found = same_kp = same_maps = n = 0
     l2 = hm = 0.0
-    for i in picks:
-        o, d = oracle.process_reference(sd, *[inp[k][i:i + 1] for k in ARGS])
+    for i, (o, d) in prefs.items():
         f = d["scores"][0] >= 0
         found += int(f.sum())
         n += 7
         hm = max(hm, float((out["hm"][i:i + 1].cpu() - o["hm"]).abs().max()))
-        same_int += int(np.array_equal(dets["xs"][i].cpu().numpy(), d["xs"][0]) and
-                        np.array_equal(dets["ys"][i].cpu().numpy(), d["ys"][0]))
-        if f.any():
-            l2 = max(l2, float(np.sqrt(((kp[i][f, :2] - d["cts_wreg"][0].reshape(7, 2)[f]) ** 2).sum(1)).max()))
+        same_maps += int(np.array_equal(xs[i], d["xs"][0]) and np.array_equal(ys[i], d["ys"][0]))
+        hit = f & (sc[i] >= 0) & (xs[i] == d["xs"][0]) & (ys[i] == d["ys"][0])
+        same_kp += int(hit.sum())
+        if hit.any():
+            l2 = max(l2, float(np.sqrt(((kp[i][hit, :2] - d["cts_wreg"][0].reshape(7, 2)[hit]) ** 2).sum(1)).max()))
+    del model, det
+    torch.cuda.empty_cache()
     return {"weights": "peaked set (hm.2.weight x %g, bias %g)" % (PEAKED_HM_GAIN, PEAKED_HM_BIAS),
-            "samples_of_benched_batch": list(picks), "keypoints_found_ref": found, "keypoints_total": n,
-            "integer_peaks_identical": same_int == len(picks), "keypoint_l2_max_px": l2, "hm_max_abs": hm}
+            "samples_of_benched_batch": sorted(prefs), "keypoints_found_ref": found, "keypoints_total": n,
+            "keypoints_same_integer_peak": same_kp, "integer_peaks_identical": same_maps == len(prefs),
+            "keypoint_l2_max_px_on_shared_peaks": l2, "hm_max_abs": hm}
 
 
 def dry_run(args):
@@ -302,6 +330,68 @@ def dry_run(args):
 
 
 # ---------------------------------------------------------------------------------------------------------
+def roofline_record(local_step, dtype, wl, el_ms, breakdown=False):
+    """Per-kernel durations of a LOCAL (collective-free) instrumented pass -> (roofline of the dominant kernel, per-kernel
+    list, kernels without a FLOP / byte model)."""
+    peak = PEAK_TFLOPS_F32_MFMA if dtype == "f32" else PEAK_TFLOPS_BF16_MFMA      # fp16 and bf16 MFMA run at the same rate
+    agg = instrumented_pass(local_step, 2)
+    tot = sum(a["ms"] for a in agg.values())
+    rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    if breakdown:
+        log("%-44s %8s %6s %9s %9s" % ("kernel (C-ABI entry / template)", "ms/step", "share", "TFLOP/s", "GB/s"))
+        for k, a in rows:
+            tf = a["flops"] / a["ms"] / 1e9 if a["flops"] else 0
+            gb = a["bytes"] / a["ms"] / 1e6 if a["bytes"] else 0
+            log("%-44s %8.3f %5.1f%% %9.1f %9.0f  x%d" % (k, a["ms"], 100 * a["ms"] / tot, tf, gb, a["launches"]))
+        log("sum of kernel time %.2f ms/step (event-bracketed), timed region %.2f ms/step" % (tot, el_ms))
+    top, ta = next((k, a) for k, a in rows if a["flops"] or a["bytes"])
+    eff = ta["flops"] / ta["ms"] / 1e9                     # TFLOP/s, algorithmic (direct-form, un-padded) flops
+    exe = ta["exec_flops"] / ta["ms"] / 1e9                # TFLOP/s actually issued to the matrix pipe
+    gbs = ta["bytes"] / ta["ms"] / 1e6                     # GB/s of algorithmic (compulsory) bytes
+    mfma_frac, hbm_frac = exe / peak, gbs / PEAK_HBM_GBS
+    bound = "hbm" if hbm_frac > mfma_frac else "mfma"
+    traffic, tnote, tcommit = pmc_traffic(top, wl)
+    if traffic is not None:
+        traffic = round(traffic / max(1, ta["launches"]))
+    roof = {
+        "kernel": top, "bound": bound,
+        "achieved": round(gbs if bound == "hbm" else exe, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak,
+        "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+        "frac": round(hbm_frac if bound == "hbm" else mfma_frac, 4),
+        "traffic": traffic, "traffic_note": tnote, "traffic_commit": tcommit,
+        "effective_tflops": round(eff, 2), "executed_tflops": round(exe, 2), "mfma_frac": round(mfma_frac, 4),
+        "alg_GBs": round(gbs, 1), "hbm_frac": round(hbm_frac, 4),
+        "note": "frac = work actually issued / peak of the binding unit (never > 1): executed matrix FLOPs (a Winograd "
+                "kernel issues 16/36 or 36/144 of the direct-form multiplies) / MFMA peak, or algorithmic bytes / HBM "
+                "peak; effective_tflops = direct-form algorithmic FLOPs / time",
+        "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
+        "share_of_step": round(ta["ms"] / tot, 3)}
+    kernels = []
+    for k, a in rows:
+        if a["flops"]:
+            kernels.append({"kernel": k, "ms_per_step": round(a["ms"], 3),
+                            "tflops": round(a["flops"] / a["ms"] / 1e9, 2),
+                            "executed_tflops": round(a["exec_flops"] / a["ms"] / 1e9, 2),
+                            "mfma_frac": round(a["exec_flops"] / a["ms"] / 1e9 / peak, 4),
+                            "alg_GBs": round(a["bytes"] / a["ms"] / 1e6, 1),
+                            "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
+    other = {k: round(a["ms"], 3) for k, a in rows if not a["flops"]}
+    return roof, kernels, other
+
+
+def timed_steps(run_step, barrier, steps, warmup):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize -> (seconds, host enqueue seconds)."""
+    for _ in range(warmup):
+        run_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    enq = time.perf_counter() - t0                  # host time to ENQUEUE the K steps (the launches are asynchronous)
+    barrier()
+    return time.perf_counter() - t0, enq
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -314,9 +404,18 @@ def main():
                     help="dlapawd3_34 = the reference's three-frame variant (frame triples/s); dlapawdT_34 = its generalisation "
                          "to a window of --frames frames (BASELINE configs[4]: --frames 4); neither is the headline metric")
     ap.add_argument("--frames", type=int, default=4, help="temporal window length of dlapawdT_34 (previous frames + current)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
                     help="f32 = BASELINE configs[1] (the headline); bf16 = configs[2]'s data path (bf16 feature maps / "
-                         "weights on bf16 MFMA, fp32 accumulate / softmax / LayerNorm / decode)")
+                         "weights on bf16 MFMA, fp32 accumulate / softmax / LayerNorm / decode); f16 = the same data path "
+                         "on IEEE half (an eighth of bf16's rounding error, same speed)")
+    ap.add_argument("--secondary", default=None,
+                    help="comma list of further compute dtypes timed in the same process after the primary one and reported "
+                         "under 'secondary' (default: bf16,f16 for the default single-GPU fp32 two-frame workload, else none)")
+    ap.add_argument("--sustained-steps", type=int, default=60,
+                    help="a second, longer timed region of the primary dtype reported as sustained_value (0: skip)")
+    ap.add_argument("--mode", default="batch", choices=["batch", "stream"],
+                    help="stream = the reference's operating point: ONE camera, frame after frame, closed loop on the device "
+                         "(pre-process -> network -> decode -> post-process -> PnP -> next priors); reports ms/frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--early-levels", default=None,
@@ -334,6 +433,8 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))     # parent: never touches the GPU
     if args.dry_run:
         return dry_run(args)
+    if args.mode == "stream":
+        return stream_mode(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -348,20 +449,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.distributed import gather_keypoints
     from sgtapose_amd.synthetic import make_inputs
     B, H, W = args.batch, args.height, args.width
-    model, sd = build_model(dev, arch=args.arch, frames=args.frames)
     seq = args.arch == "dlapawdT_34"
     three = args.arch == "dlapawd3_34" or seq
-    if args.dtype == "bf16":
-        model.engine_dtype = "bf16"
     if three:
         args.no_cpu_baseline = True                 # the CPU baseline / parity leg is the two-frame oracle's
-    eng = model.engine()
-    eng.compute_dead_levels = not args.skip_dead_levels
-    if args.early_levels is not None:
-        eng.early_levels = tuple(int(v) for v in args.early_levels.split(",") if v != "")
-    det = BatchedDetector(model)
     if seq:
         from sgtapose_amd.synthetic import SEQ_ARGS, make_inputs_seq
         inp = make_inputs_seq(B, H, W, T=args.frames, seed=317 + rank * B)
@@ -373,49 +467,65 @@ def main():
     else:
         inp = make_inputs(B, H, W, seed=317 + rank * B)        # this rank's shard of the global batch
         dev_in = [inp[k].to(dev) for k in ARGS]
-    from sgtapose_amd.distributed import gather_keypoints
-    state = {}
-
-    def local_step():
-        out, dets = det.process_device(*dev_in, static=True)
-        state["out"], state["dets"], state["kp"] = out, dets, det.keypoints(dets)
-
-    def run_step():
-        local_step()
-        # the path's only exchange step: all-gather of the [B,7,3] keypoints (RCCL when world > 1)
-        state["kp_all"] = gather_keypoints(state["kp"], world * B)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        run_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step()
-    enq = time.perf_counter() - t0                  # host time to ENQUEUE the K steps (the launches are asynchronous)
-    barrier()
-    el = time.perf_counter() - t0
-    ranks_seen = 1
+    def workload(dtype):
+        """Model + detector of one compute dtype and its step functions."""
+        model, sd = build_model(dev, arch=args.arch, frames=args.frames)
+        model.engine_dtype = dtype
+        eng = model.engine()
+        eng.compute_dead_levels = not args.skip_dead_levels
+        if args.early_levels is not None:
+            eng.early_levels = tuple(int(v) for v in args.early_levels.split(",") if v != "")
+        det = BatchedDetector(model)
+        state = {}
+
+        def local_step():
+            out, dets = det.process_device(*dev_in, static=True)
+            state["out"], state["dets"], state["kp"] = out, dets, det.keypoints(dets)
+
+        def run_step():
+            local_step()
+            # the path's only exchange step: all-gather of the [B,7,3] keypoints (RCCL when world > 1)
+            state["kp_all"] = gather_keypoints(state["kp"], world * B)
+
+        return dict(model=model, sd=sd, eng=eng, det=det, state=state, local_step=local_step, run_step=run_step)
+
+    wk = workload(args.dtype)
+    state = wk["state"]
+    el, enq = timed_steps(wk["run_step"], barrier, args.steps, args.warmup)
+    ranks_seen, kp_sums_equal = 1, True
     if dist is not None:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
         ranks_seen = dist.get_world_size()
         assert tuple(state["kp_all"].shape) == (world * B, 7, 3)
+        # outside the timed region: every rank must hold the SAME gathered key-point tensor
+        cs = state["kp_all"].double().nan_to_num().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        kp_sums_equal = bool(lo.item() == hi.item())
+        if rank == 0 and (ranks_seen != world or not kp_sums_equal):
+            raise SystemExit("multi-rank check failed: ranks_seen %d of %d, gathered key-points equal on all ranks: %s"
+                             % (ranks_seen, world, kp_sums_equal))
 
+    unit_name = ("frame-windows(T=%d)" % args.frames) if seq else ("frame-triples" if three else "frame-pairs")
     cfg_name = {(32, 480, 640, "f32"): "configs[1]", (32, 480, 640, "bf16"): "configs[2] per-GPU shard (32 pairs, bf16)",
+                (32, 480, 640, "f16"): "configs[2] per-GPU shard on IEEE half (32 pairs, f16)",
                 (16, 736, 1280, "f32"): "configs[3] (720p padded to a multiple of 32)"}.get((B, H, W, args.dtype), "custom")
     if three:
         cfg_name = "three-frame variant dlapawd3_34 (seq_len 3: the reference's widest; towards configs[4])"
     if seq:
         cfg_name = "configs[4] per-GPU shard: temporal window of %d frames (prev-%d + curr), dlapawdT_34" % (args.frames, args.frames - 1)
+    what = ("%d-frame windows" % args.frames) if seq else ("3-frame triples" if three else "2-frame pairs")
     result = {
-        "metric": "%s/sec @%dx%d" % (("frame-windows(T=%d)" % args.frames) if seq else ("frame-triples" if three else "frame-pairs"),
-                                      args.height, args.width),
+        "metric": "%s/sec @%dx%d" % (unit_name, args.height, args.width),
         "value": round(world * B * args.steps / el, 3),
         "unit": "frame-windows/s" if seq else ("frame-triples/s" if three else "frame-pairs/s"),
         "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
@@ -423,78 +533,92 @@ def main():
         "host_enqueue_ms_per_step": round(1e3 * enq / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": cfg_name + ": batch=%d 2-frame %dx%d synthetic pairs per GPU, %s random-init (seeded), "
+        "config": {"workload": cfg_name + ": batch=%d synthetic %s of %dx%d per GPU, %s random-init (seeded), "
                                "full backbone + temporal attention (6 levels) + DCN neck + heads + sigmoid + peak "
-                               "decode%s" % (B, H, W, args.arch, " + RCCL all-gather of keypoints" if world > 1 else ""),
+                               "decode%s" % (B, what, H, W, args.arch, " + RCCL all-gather of keypoints" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": world * B, "net_input": [H, W],
                    "parallelism": "dp%d (batch shards, weights replicated)" % world,
                    "dead_levels_computed": not args.skip_dead_levels,
-                   "workspace_GB": round(eng.workspace_bytes() / 2 ** 30, 2)},
+                   "workspace_GB": round(wk["eng"].workspace_bytes() / 2 ** 30, 2)},
     }
+    if world > 1:
+        result["gathered_keypoints_equal_on_all_ranks"] = kp_sums_equal
+    if args.sustained_steps > 0:
+        # a longer region right behind the contract's K steps (clocks settled, no warm-up effects): the sustained rate
+        el2, _ = timed_steps(wk["run_step"], barrier, args.sustained_steps, 0)
+        if dist is not None:
+            tt = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el2 = float(tt.item())
+        result["sustained_value"] = round(world * B * args.sustained_steps / el2, 3)
+        result["sustained_steps"] = args.sustained_steps
 
     # everything below is rank-0-only and collective-free (the other ranks wait in the final barrier)
+    wl = {"batch": B, "height": H, "width": W, "arch": args.arch, "dtype": args.dtype}
     if rank == 0 and not args.no_roofline:
-        peak = PEAK_TFLOPS_BF16_MFMA if args.dtype == "bf16" else PEAK_TFLOPS_F32_MFMA
-        agg = instrumented_pass(local_step, 2)
-        tot = sum(a["ms"] for a in agg.values())
-        rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
-        if args.breakdown:
-            log("%-44s %8s %6s %9s %9s" % ("kernel (C-ABI entry / template)", "ms/step", "share", "TFLOP/s", "GB/s"))
-            for k, a in rows:
-                tf = a["flops"] / a["ms"] / 1e9 if a["flops"] else 0
-                gb = a["bytes"] / a["ms"] / 1e6 if a["bytes"] else 0
-                log("%-44s %8.3f %5.1f%% %9.1f %9.0f  x%d" % (k, a["ms"], 100 * a["ms"] / tot, tf, gb, a["launches"]))
-            log("sum of kernel time %.2f ms/step (event-bracketed), timed region %.2f ms/step" % (tot, 1e3 * el / args.steps))
-        top, ta = next((k, a) for k, a in rows if a["flops"] or a["bytes"])
-        eff = ta["flops"] / ta["ms"] / 1e9                     # TFLOP/s, algorithmic (direct-form, un-padded) flops
-        exe = ta["exec_flops"] / ta["ms"] / 1e9                # TFLOP/s actually issued to the matrix pipe
-        gbs = ta["bytes"] / ta["ms"] / 1e6                     # GB/s of algorithmic (compulsory) bytes
-        mfma_frac, hbm_frac = exe / peak, gbs / PEAK_HBM_GBS
-        bound = "hbm" if hbm_frac > mfma_frac else "mfma"
-        wl = {"batch": B, "height": H, "width": W, "arch": args.arch, "dtype": args.dtype}
-        traffic, tnote, tcommit = pmc_traffic(top, wl)
-        if traffic is not None:
-            traffic = round(traffic / max(1, ta["launches"]))
-        result["roofline"] = {
-            "kernel": top, "bound": bound,
-            "achieved": round(gbs if bound == "hbm" else exe, 2), "peak": PEAK_HBM_GBS if bound == "hbm" else peak,
-            "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-            "frac": round(hbm_frac if bound == "hbm" else mfma_frac, 4),
-            "traffic": traffic, "traffic_note": tnote, "traffic_commit": tcommit,
-            "effective_tflops": round(eff, 2), "executed_tflops": round(exe, 2), "mfma_frac": round(mfma_frac, 4),
-            "alg_GBs": round(gbs, 1), "hbm_frac": round(hbm_frac, 4),
-            "note": "frac = work actually issued / peak of the binding unit (never > 1): executed matrix FLOPs (a Winograd "
-                    "kernel issues 16/36 or 36/144 of the direct-form multiplies) / MFMA peak, or algorithmic bytes / HBM "
-                    "peak; effective_tflops = direct-form algorithmic FLOPs / time",
-            "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
-            "share_of_step": round(ta["ms"] / tot, 3)}
-        extra = []
-        for k, a in rows:
-            if a["flops"]:
-                extra.append({"kernel": k, "ms_per_step": round(a["ms"], 3),
-                              "tflops": round(a["flops"] / a["ms"] / 1e9, 2),
-                              "executed_tflops": round(a["exec_flops"] / a["ms"] / 1e9, 2),
-                              "mfma_frac": round(a["exec_flops"] / a["ms"] / 1e9 / peak, 4),
-                              "alg_GBs": round(a["bytes"] / a["ms"] / 1e6, 1),
-                              "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
-        result["kernels"] = extra
-        result["other_kernels_ms"] = {k: round(a["ms"], 3) for k, a in rows if not a["flops"]}
+        result["roofline"], result["kernels"], result["other_kernels_ms"] = roofline_record(
+            wk["local_step"], args.dtype, wl, 1e3 * el / args.steps, args.breakdown)
 
+    refs = prefs = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        local_step()
+        wk["local_step"]()
         torch.cuda.synchronize()
-        cb, refs = cpu_baseline(sd, inp, state["out"], state["dets"])
+        cb, refs = cpu_reference(wk["sd"], inp)
+        cb["parity"] = batch_parity(refs, state["out"], state["dets"], args.dtype)
         # samples of the seeded configs[1] batch in which the reference finds key-points with the peaked weight set
         # (scanned offline with the oracle: 3 / 2 / 2 key-points); any other workload: first / middle / last
         picks = (7, 9, 30) if (B, H, W, rank) == (32, 480, 640, 0) else sorted(refs)[::2][:3]
-        cb["parity"]["peaked_weights"] = peaked_parity(dev, inp, picks, args.dtype)
+        prefs = peaked_reference(inp, picks)
+        cb["parity"]["peaked_weights"] = peaked_parity(dev, inp, prefs, args.dtype)
         result["cpu_baseline"] = cb
+        result["parity_ok"] = bool(cb["parity"]["within_bar"] and (args.dtype != "f32" or (
+            cb["parity"]["integer_peaks_identical"] and cb["parity"]["peaked_weights"]["integer_peaks_identical"])))
+
+    # ---- further compute dtypes of the SAME workload, timed in this process with the same K / W and bracket ---------------
+    sec = args.secondary
+    if sec is None:
+        sec = "bf16,f16" if (world == 1 and args.dtype == "f32" and not three and (B, H, W) == (32, 480, 640)) else ""
+    sec = [d for d in sec.split(",") if d and d != args.dtype]
+    if rank == 0 and world == 1 and sec:
+        wk["eng"].bufs.clear()
+        del wk
+        torch.cuda.empty_cache()
+        result["secondary"] = {}
+        for dt in sec:
+            w2 = workload(dt)
+            el_s, enq_s = timed_steps(w2["run_step"], barrier, args.steps, args.warmup)
+            rec = {"dtype": dt, "value": round(B * args.steps / el_s, 3), "unit": result["unit"], "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": round(1e3 * el_s / args.steps, 3),
+                   "host_enqueue_ms_per_step": round(1e3 * enq_s / args.steps, 3),
+                   "workload": "the primary workload (batch=%d, %dx%d, %s) on the %s data path" % (B, H, W, args.arch, dt)}
+            if args.sustained_steps > 0:
+                el2, _ = timed_steps(w2["run_step"], barrier, args.sustained_steps, 0)
+                rec["sustained_value"] = round(B * args.sustained_steps / el2, 3)
+            if not args.no_roofline:
+                rec["roofline"], rec["kernels"], _ = roofline_record(w2["local_step"], dt, dict(wl, dtype=dt),
+                                                                      1e3 * el_s / args.steps, args.breakdown)
+            if refs is not None:
+                w2["local_step"]()
+                torch.cuda.synchronize()
+                rec["parity"] = batch_parity(refs, w2["state"]["out"], w2["state"]["dets"], dt)
+                rec["parity"]["peaked_weights"] = peaked_parity(dev, inp, prefs, dt)
+                rec["parity_ok"] = rec["parity"]["within_bar"]
+            result["secondary"][dt] = rec
+            w2["eng"].bufs.clear()
+            del w2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and result.get("parity_ok") is False:
+        raise SystemExit(4)                         # a step whose outputs leave the dtype's bar is not a valid measurement
+
+
+def stream_mode(args):
+    raise SystemExit("--mode stream is not built yet")
 
 
 if __name__ == "__main__":

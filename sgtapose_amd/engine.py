@@ -46,6 +46,20 @@ class CachedStem:
 
 
 
+# Side streams are shared by every engine of a process (one set per device): HIP maps streams onto a handful of hardware
+# queues, and an engine that took fresh streams of its own could land two streams that are meant to overlap on one queue
+# (measured: the second and third engine built in one process ran 3-6 % slower than the first).
+_STREAMS = {}
+
+
+def shared_stream(dev, name):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), name)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=dev)        # every stream at the default priority
+    return st
+
+
 class Engine:
     def __init__(self, model):
         p = next(model.parameters())
@@ -145,10 +159,7 @@ class Engine:
     split_parts = 2
 
     def _part_streams(self, n):
-        st = getattr(self, "_pstreams", None)
-        if st is None or len(st) < n:
-            st = self._pstreams = [torch.cuda.Stream(device=self.dev) for _ in range(n)]
-        return st[:n]
+        return [shared_stream(self.dev, "part%d" % k) for k in range(n)]
 
     def buf(self, name, shape, dtype=torch.float32):
         key = (name + self.buf_tag, tuple(shape), dtype)
@@ -478,11 +489,7 @@ class Engine:
         return View(v.base[k * B:(k + 1) * B])
 
     def _neck_stream(self):
-        if getattr(self, "_side2", None) is None:
-            self._side2 = torch.cuda.Stream(device=self.dev)        # every stream at the default priority
-        return self._side2
+        return shared_stream(self.dev, "neck")
 
     def _side_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        return self._side
+        return shared_stream(self.dev, "side")

@@ -238,8 +238,8 @@ def test_heads_fused_f16(bops, N, H, W, npf):
 
 
 # ---- network level ---------------------------------------------------------------------------------------------------
-F16_LOGIT_TOL = 8e-3        # max |logit_f16 - logit_fp32 oracle| on hm / reg / tracking (bf16 path: 6e-2)
-F16_LOGIT_MEAN_TOL = 1e-3   # mean (bf16 path: 8e-3)
+F16_LOGIT_TOL = 1.2e-2      # max |logit_f16 - logit_fp32 oracle| on hm / reg / tracking (measured 2e-3 .. 6e-3; bf16 path: 6e-2)
+F16_LOGIT_MEAN_TOL = 1.5e-3 # mean (measured 3e-4 .. 6e-4; bf16 path: 8e-3)
 
 
 def _f16_model(peaked=False):
@@ -319,3 +319,44 @@ def test_f16_step_is_deterministic_across_streams():
             for k in first:
                 assert torch.equal(first[k], cur[k]), (i, k)
     torch.cuda.synchronize()
+
+
+def test_f16_keypoints_on_peaked_weights_match_the_reference():
+    """network -> sigmoid -> decode on IEEE half with the peaked weight set (hm logits x 30): of the key-points the fp32
+    oracle finds, at least 90 % reappear at the SAME integer peak, and on those (x + reg_x, y + reg_y) agrees to 0.05 px.
+    (bf16's logit noise, eight times larger, does not preserve this set's marginal peaks: test_bf16_parity.py.)"""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _f16_model(peaked=True)
+    found = same = 0
+    l2 = 0.0
+    for seed, B in ((11, 4), (23, 6)):
+        inp = make_inputs(B, 128, 160, seed=seed)
+        out, dets = BatchedDetector(m).process_device(*[inp[k].to(DEV) for k in ARGS])
+        _, rd = oracle.process_reference(golden_state_dict(0, peaked=True), *[inp[k] for k in ARGS])
+        xs, ys, sc = dets["xs"].cpu().numpy(), dets["ys"].cpu().numpy(), dets["scores"].cpu().numpy()
+        f = rd["scores"] >= 0
+        hit = f & (sc >= 0) & (xs == rd["xs"]) & (ys == rd["ys"])
+        found += int(f.sum())
+        same += int(hit.sum())
+        if hit.any():
+            l2 = max(l2, float(np.sqrt(((dets["cts_wreg"].cpu().numpy() - rd["cts_wreg"])[hit] ** 2).sum(1)).max()))
+    print("f16 peaked: reference key-points %d, same integer peak %d, sub-pixel L2 max %.2e px" % (found, same, l2))
+    assert found >= 5 and same >= 0.9 * found and l2 <= 0.05
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_decode_of_the_16bit_paths_own_heat_maps_is_exact(dtype):
+    """Whatever noise a 16-bit network puts on the heat-maps, the DECODE stays exact: the device decode of the engine's
+    own outputs equals the oracle's decode of those same maps (integer peaks and scores bit for bit, offsets to 1e-6)."""
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _f16_model(peaked=True)
+    m.engine_dtype = dtype
+    inp = make_inputs(6, 128, 160, seed=23)
+    out, dets = BatchedDetector(m).process_device(*[inp[k].to(DEV) for k in ARGS])
+    rd = oracle.dream_decode({k: v.cpu() for k, v in out.items()}, K=7)
+    assert int((rd["scores"] >= 0).sum()) >= 1
+    assert np.array_equal(dets["xs"].cpu().numpy(), rd["xs"].numpy()) and np.array_equal(dets["ys"].cpu().numpy(), rd["ys"].numpy())
+    assert torch.equal(dets["scores"].cpu(), rd["scores"])
+    assert float((dets["cts_wreg"].cpu() - rd["cts_wreg"]).abs().max()) <= 1e-6
