@@ -618,7 +618,75 @@ def main():
 
 
 def stream_mode(args):
-    raise SystemExit("--mode stream is not built yet")
+    """--mode stream: the reference's own operating point (SGTADetector.run, sgta_detector.py:117-236 under inference_real,
+    inference.py:209-222): B cameras (default 1) in lock-step, frame after frame, the whole loop on the device
+    (sgtapose_amd.stream.VideoRunner).  Per compute dtype, eager launches and HIP-graph replay:
+      latency_ms    host-observed time of one frame, synchronised every frame: H2D of the raw uint8 frame + the step +
+                    D2H of the [B,7,2] key-point table (median / p90 over --steps frames)
+      frames_per_s  the same loop enqueued without per-frame synchronisation (the loop's frame-to-frame dependency lives
+                    on the device, so the host may run ahead)
+      host_enqueue_ms  host time to enqueue one frame (what bounds the eager form at small batch)."""
+    import numpy as np
+    from sgtapose_amd.stream import VideoRunner
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    B, H, W = (args.batch if args.batch != 32 else 1), args.height, args.width
+    steps, warm = max(args.steps, 20), max(args.warmup, 6)
+    g = torch.Generator().manual_seed(317)
+    frames = [torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(8)]
+    pts = np.array([[0, 0, 0], [0.1, 0.05, 0.3], [-0.15, 0.1, 0.25], [0.2, -0.1, 0.1], [-0.1, -0.15, 0.2], [0.05, 0.2, 0.05],
+                    [0.25, 0.15, 0.35]], np.float64)
+    x3d = np.stack([pts] * B)
+    camK = np.array([[0.94 * W, 0, W / 2.0], [0, 0.94 * W, H / 2.0], [0, 0, 1.0]])
+    dtypes = [args.dtype] + [d for d in (args.secondary if args.secondary is not None else "bf16,f16").split(",")
+                             if d and d != args.dtype]
+    rec = {}
+    for dt in dtypes:
+        from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+        from util import golden_state_dict
+        model = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(),
+                             default_opt(input_h=H, input_w=W, fix_res=True))
+        model.load_state_dict(golden_state_dict(0, peaked=True), strict=True)
+        model = model.to(dev).eval()
+        model.engine_dtype = dt
+        rec[dt] = {}
+        for use_graph in (False, True):
+            r = VideoRunner(model, (H, W), camK, batch=B, use_graph=use_graph)
+            for i in range(warm):
+                r.step(frames[i % 8], x3d)
+            lat = []
+            for i in range(steps):
+                t0 = time.perf_counter()
+                r.step(frames[i % 8], x3d)
+                lat.append(1e3 * (time.perf_counter() - t0))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                r.step(frames[i % 8], x3d, sync=False)
+            enq = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            lat.sort()
+            rec[dt]["graph" if use_graph else "eager"] = {
+                "latency_ms_median": round(_median(lat), 3), "latency_ms_p90": round(lat[int(0.9 * (len(lat) - 1))], 3),
+                "frames_per_s": round(B * steps / el, 1), "host_enqueue_ms": round(1e3 * enq / steps, 3)}
+            log("stream %-4s %-5s latency %.2f ms (p90 %.2f)  pipelined %.0f frames/s  host enqueue %.2f ms/frame"
+                % (dt, "graph" if use_graph else "eager", _median(lat), lat[int(0.9 * (len(lat) - 1))], B * steps / el,
+                   1e3 * enq / steps))
+            del r
+        model.engine().bufs.clear()
+        del model
+        torch.cuda.empty_cache()
+    best = rec[args.dtype]["graph"]
+    print(json.dumps({
+        "metric": "ms/frame, closed-loop video at %dx%d, %d camera(s): raw uint8 frame in -> key-point table out" % (H, W, B),
+        "value": best["latency_ms_median"], "unit": "ms", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": best["latency_ms_median"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "stream mode (the reference's SGTADetector.run loop): pre-process -> PnP priors -> two-frame "
+                               "network -> decode -> post-process per frame, state on the device; HIP-graph replay",
+                   "cameras": B, "net_input": [H, W]},
+        "stream": rec}), flush=True)
 
 
 if __name__ == "__main__":

@@ -299,6 +299,11 @@ int sgta_post_process(const float* scores, const long long* cts, const float* ct
                       float* ct, float* ct_wreg, float* reg, float* trk, double* final_kps, int B, int K,
                       sgta_stream_t stream);
 
+/* has[b] (u8 [B]) = 1 iff final_kps [B,K,2] (f64, sgta_post_process) holds a detected key-point for sample b, i.e. a coordinate
+ * above the missing marker -999.999*4: SGTADetector._get_further_dt_pnp_inputs (sgtapose/lib/sgta_detector.py:471-479) feeds
+ * all-zero prior maps to the next frame otherwise.  ``has`` is sgta_render_priors' has_prior. */
+int sgta_kps_any_valid(const double* final_kps, unsigned char* has, int B, int K, sgta_stream_t stream);
+
 /* SGTADetector.pre_process (sgtapose/lib/sgta_detector.py:368-399, normalize_img :401-402) for a batch of raw frames of
  * one size: cv2.warpAffine(image, trans_input, (Wo, Ho), INTER_LINEAR, constant border 0) + (img / 255 - mean) / std in
  * float32 + HWC -> CHW.  images u8 [B,Hr,Wr,3]; inv_trans f64 [B,2,3] = the INVERSE of meta['trans_input'] (computed by

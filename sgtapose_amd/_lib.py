@@ -46,6 +46,7 @@ SIGNATURES = {
     "sgta_peaks_decode_kp_static": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_peaks_decode_static_max_elems": [],
     "sgta_render_priors": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "sgta_kps_any_valid": [_p, _p, _i, _i, _p],
     "sgta_post_process": [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "sgta_conv_bf16": [_p, _l, _l, _p, _l, _p, _p, _l, _p, _l] + [_i] * 14 + [_p],
     "sgta_dcnv2_fwd_bf16": [_p, _l, _p, _i, _p, _l, _p, _p, _l] + [_i] * 9 + [_p],

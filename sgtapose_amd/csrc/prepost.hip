@@ -61,6 +61,25 @@ extern "C" int sgta_render_priors(const double* kps, const double* trans, const 
   return SGTA_OK;
 }
 
+// has[b] = 1 iff sample b holds at least one detected key-point (a coordinate above the detector's missing marker
+// -999.999 * 4): SGTADetector._get_further_dt_pnp_inputs returns all-zero prior maps otherwise
+// (sgtapose/lib/sgta_detector.py:471-479).  Keeps that decision on the device in a closed video loop.
+__global__ __launch_bounds__(64) void kps_any_valid_kernel(const double* __restrict__ kps, unsigned char* __restrict__ has,
+                                                            int B, int K) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  bool any = false;
+  for (int i = 0; i < 2 * K; ++i) any = any || kps[(long)b * 2 * K + i] > -999.999 * 4;
+  has[b] = any ? 1 : 0;
+}
+
+extern "C" int sgta_kps_any_valid(const double* final_kps, unsigned char* has, int B, int K, hipStream_t st) {
+  if (!final_kps || !has || B <= 0 || K <= 0) return SGTA_EBADARG;
+  hipLaunchKernelGGL(kps_any_valid_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, final_kps, has, B, K);
+  SGTA_LAUNCH_CHECK();
+  return SGTA_OK;
+}
+
 // One thread per (sample, class).  trans_inv [B,2,3] fp32 (the reference casts it, post_process.py:103).
 __global__ __launch_bounds__(64) void post_process_kernel(const float* __restrict__ scores,
                                                           const long long* __restrict__ cts,

@@ -1,0 +1,158 @@
+"""GPU (-m gpu): the reference's operating point -- one camera, frame after frame, closed loop -- through
+``sgtapose_amd.stream.VideoRunner`` against the ORACLE CHAIN of the same loop on the CPU (SGTADetector.run,
+sgtapose/lib/sgta_detector.py:117-236):
+
+    oracle.prepost.pre_process -> priors (first frame / no detections: zeros; else oracle.pnp.is_pnp + the four rendered
+    maps) -> oracle.process_reference -> oracle.prepost.dream_generic_post_process -> get_final_kps
+
+Every frame: the same integer peaks, the same detected / missing table, key-points to 1e-3 px, heat-maps to 1e-3.  The
+first frame has all-zero priors (every attention window at pixel (0, 0): the duplicate-scatter case).  The HIP-graph form
+of the loop must reproduce the eager form bit for bit on every replay.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import pnp as opnp
+from oracle import prepost as opp
+from util import golden_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+MISSING = -999.999 * 4
+HR, WR, INP_H, INP_W = 120, 160, 128, 160          # raw frame / network input (letter-boxed by the affine warp)
+CAM_K = np.array([[150.0, 0, 80.0], [0, 150.0, 60.0], [0, 0, 1.0]])
+
+
+def _robot(T):
+    """7 rigid key-points ~1.4 m in front of the camera, drifting a little from frame to frame -> ([T,7,3] in the robot
+    frame -- constant --, [T,7,2] their raw-image projections under the frame's pose)."""
+    g = np.random.default_rng(5)
+    pts = np.array([[0, 0, 0], [0.1, 0.05, 0.3], [-0.15, 0.1, 0.25], [0.2, -0.1, 0.1], [-0.1, -0.15, 0.2], [0.05, 0.2, 0.05],
+                    [0.25, 0.15, 0.35]], np.float64)
+    x3d, proj = [], []
+    for t in range(T):
+        a = 0.05 * t
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        tr = np.array([0.02 * t - 0.05, 0.01 * t - 0.03, 1.4])
+        cam = pts @ R.T + tr
+        uv = cam @ CAM_K.T
+        proj.append(uv[:, :2] / uv[:, 2:3] + g.normal(0, 0.3, (7, 2)))
+        x3d.append(pts.copy())
+    return np.stack(x3d), np.stack(proj)
+
+
+def _frames(T, B=1, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 256, (B, HR, WR, 3), generator=g, dtype=torch.uint8) for _ in range(T)]
+
+
+def _model(peaked=True, dtype="f32"):
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt(input_h=INP_H, input_w=INP_W, fix_res=True))
+    sd = golden_state_dict(0, peaked=peaked)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = dtype
+    return m, sd
+
+
+def _oracle_loop(sd, frames, x3ds, out_thresh, seeds, proj=None):
+    """``seeds`` {frame: key-points the frame's priors start from} is extended on the way when ``proj`` is given: a frame
+    whose NATURAL detections would give PnP four or more points is seeded with the robot's true projections instead --
+    the random-init network's detections are not consistent with any pose, and PnP on an inconsistent 4-point problem
+    is ill-posed (two correct solvers end in different minima), which is not what this test is about."""
+    c, s = np.array([WR / 2.0, HR / 2.0], np.float32), max(HR, WR) * 1.0
+    t_in = opp.get_affine_transform(c, s, 0, [INP_W, INP_H])
+    t_out = opp.get_affine_transform(c, s, 0, [INP_W // 4, INP_H // 4])
+    t_inv = opp.get_affine_transform(c, s, 0, (INP_W // 4, INP_H // 4), inv=1).astype(np.float32)
+    kps, prev_img, rec = None, None, []
+    for i, fr in enumerate(frames):
+        img = opp.pre_process(fr[0].numpy(), t_in, INP_W, INP_H)
+        if i in seeds:
+            kps = seeds[i].copy()
+        z = lambda ch, h, w: torch.zeros(1, ch, h, w)                                   # noqa: E731
+        pre_hm, repro_hm = z(1, INP_H, INP_W), z(1, INP_H, INP_W)
+        pre_cls, repro_cls = z(7, INP_H // 4, INP_W // 4), z(7, INP_H // 4, INP_W // 4)
+        if kps is not None:
+            good = np.unique(np.where(kps > MISSING)[0])
+            if len(good):
+                prev_all, nxt = opnp.is_pnp(x3ds[i - 1][good], kps[good], x3ds[i], kps, CAM_K)
+                f = lambda a: torch.from_numpy(np.asarray(a, np.float32))               # noqa: E731
+                pre_hm = f(opp.get_prev_hm_wo_noise(prev_all, t_in, INP_W, INP_H, WR, HR)).view(1, 1, INP_H, INP_W)
+                repro_hm = f(opp.get_prev_hm_wo_noise(nxt, t_in, INP_W, INP_H, WR, HR)).view(1, 1, INP_H, INP_W)
+                pre_cls = f(opp.get_prev_hm_wo_noise_cls(prev_all, 7, t_out, INP_W // 4, INP_H // 4, WR, HR)).view(1, 7, INP_H // 4, INP_W // 4)
+                repro_cls = f(opp.get_prev_hm_wo_noise_cls(nxt, 7, t_out, INP_W // 4, INP_H // 4, WR, HR)).view(1, 7, INP_H // 4, INP_W // 4)
+        out, dets = oracle.process_reference(sd, img, img if prev_img is None else prev_img, pre_hm, repro_hm, pre_cls, repro_cls)
+        res = opp.dream_generic_post_process(dets, [t_inv], out_thresh)
+        kps = opp.get_final_kps(res[0], 7)
+        if proj is not None and i + 1 < len(frames) and int((kps > MISSING).all(1).sum()) >= 4:
+            seeds[i + 1] = proj[i].copy()
+        prev_img = img
+        rec.append(dict(kps=kps.copy(), xs=dets["xs"][0].copy(), ys=dets["ys"][0].copy(), scores=dets["scores"][0].copy(),
+                        hm=out["hm"].clone(), priors=float(pre_hm.max()) + float(repro_cls.max())))
+    return rec
+
+
+def _run(runner, frames, x3ds, seeds):
+    rec = []
+    for i, fr in enumerate(frames):
+        if i in seeds:
+            runner.seed_keypoints(seeds[i][None], x3ds[i - 1][None])
+        kps = runner.step(fr, x3ds[i][None])
+        out, dets = runner.last
+        rec.append(dict(kps=kps[0].copy(), xs=dets["xs"][0].cpu().numpy(), ys=dets["ys"][0].cpu().numpy(),
+                        scores=dets["scores"][0].cpu().numpy(), hm=out["hm"].cpu().clone()))
+    return rec
+
+
+def test_closed_loop_video_matches_the_oracle_chain():
+    from sgtapose_amd.stream import VideoRunner
+    T = 8
+    frames = _frames(T)
+    x3ds, proj = _robot(T)
+    seeds = {4: proj[3].copy()}                    # frame 4 starts from known detections of frame 3: the PnP branch is certain
+    seeds[4][5] = MISSING                          # ... with one key-point missing
+    m, sd = _model(peaked=True)
+    ref = _oracle_loop(sd, frames, x3ds, float(m.opt.out_thresh), seeds, proj)
+    print("seeded frames:", sorted(seeds))
+    got = _run(VideoRunner(m, (HR, WR), CAM_K, batch=1), frames, x3ds, seeds)
+    n_det = n_prior = 0
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert float((a["hm"] - b["hm"]).abs().max()) <= 1e-3, i
+        assert np.array_equal(a["xs"], b["xs"]) and np.array_equal(a["ys"], b["ys"]), i
+        assert np.array_equal(a["scores"] >= 0, b["scores"] >= 0), i
+        miss = b["kps"] <= MISSING
+        assert np.array_equal(a["kps"] <= MISSING, miss), i
+        assert np.abs(a["kps"] - b["kps"])[~miss].max(initial=0.0) <= 1e-3, i
+        n_det += int((~miss).all(1).sum())
+        n_prior += int(b["priors"] > 0)
+    print("closed loop: %d frames, %d key-points detected in total, %d frames ran with non-zero priors" % (T, n_det, n_prior))
+    assert ref[0]["priors"] == 0 and n_prior >= 2 and n_det >= 3
+
+
+@pytest.mark.parametrize("dtype,B", [("f32", 1), ("f32", 2), ("f16", 1)])
+def test_graph_captured_loop_reproduces_the_eager_loop_on_every_replay(dtype, B):
+    """The steady-state step captured in a HIP graph (one per buffer parity) against the eager loop, frame by frame, with
+    the program's own eager work (seeding, host copies, synchronisation) between the replays: bit-identical."""
+    from sgtapose_amd.stream import VideoRunner
+    T = 9
+    frames = _frames(T, B=B, seed=9)
+    x3ds, proj = _robot(T)
+    m, _ = _model(peaked=True, dtype=dtype)
+    eager = VideoRunner(m, (HR, WR), CAM_K, batch=B)
+    graph = VideoRunner(m, (HR, WR), CAM_K, batch=B, use_graph=True)
+    for i, fr in enumerate(frames):
+        if i == 6:                                 # eager work between replays: re-seed both loops
+            for r in (eager, graph):
+                r.seed_keypoints(np.stack([proj[5]] * B), np.stack([x3ds[5]] * B))
+        xb = np.stack([x3ds[i]] * B)
+        ka = eager.step(fr, xb)
+        oa = {k: v.clone() for k, v in eager.last[0].items()}
+        kb = graph.step(fr, xb)
+        ob = graph.last[0]
+        assert np.array_equal(ka, kb), i
+        for k in oa:
+            assert torch.equal(oa[k], ob[k]), (i, k)
+    assert graph.graphs[0] is not None and graph.graphs[1] is not None
