@@ -123,7 +123,9 @@ def instrumented_pass(run_step, steps):
         rec, _lib.PROFILE = _lib.PROFILE, None
         for name, meta, e0, e1 in rec:
             key = meta["kernel"] if meta else name
-            a = agg.setdefault(key, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, exec_flops=0.0))
+            a = agg.setdefault(key, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0, exec_flops=0.0, peak=None))
+            if meta and meta.get("peak_tflops"):
+                a["peak"] = meta["peak_tflops"]         # a kernel that runs on another matrix pipe than the engine's dtype
             a["ms"] += e0.elapsed_time(e1)
             a["launches"] += 1
             if meta:
@@ -320,8 +322,16 @@ def dry_run(args):
     tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ok = tuple(allkp.shape) == (world * B, 7, 3) and all(float(allkp[r * B, 0, 0]) == r for r in range(world))
+    # the checks of the GPU run, outside the timed region: every rank is there and holds the SAME gathered tensor
+    cs = allkp.double().sum().reshape(1)
+    lo, hi = cs.clone(), cs.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    same = bool(lo.item() == hi.item())
+    ok = ok and same and dist.get_world_size() == args.gpus
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": dist.get_world_size(), "gather_ok": ok,
+                          "gathered_keypoints_equal_on_all_ranks": same, "dtype": args.dtype, "arch": args.arch,
                           "steps": args.steps, "warmup": args.warmup}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -345,6 +355,8 @@ def roofline_record(local_step, dtype, wl, el_ms, breakdown=False):
             log("%-44s %8.3f %5.1f%% %9.1f %9.0f  x%d" % (k, a["ms"], 100 * a["ms"] / tot, tf, gb, a["launches"]))
         log("sum of kernel time %.2f ms/step (event-bracketed), timed region %.2f ms/step" % (tot, el_ms))
     top, ta = next((k, a) for k, a in rows if a["flops"] or a["bytes"])
+    peak_engine = peak
+    peak = ta["peak"] or peak_engine
     eff = ta["flops"] / ta["ms"] / 1e9                     # TFLOP/s, algorithmic (direct-form, un-padded) flops
     exe = ta["exec_flops"] / ta["ms"] / 1e9                # TFLOP/s actually issued to the matrix pipe
     gbs = ta["bytes"] / ta["ms"] / 1e6                     # GB/s of algorithmic (compulsory) bytes
@@ -372,7 +384,8 @@ def roofline_record(local_step, dtype, wl, el_ms, breakdown=False):
             kernels.append({"kernel": k, "ms_per_step": round(a["ms"], 3),
                             "tflops": round(a["flops"] / a["ms"] / 1e9, 2),
                             "executed_tflops": round(a["exec_flops"] / a["ms"] / 1e9, 2),
-                            "mfma_frac": round(a["exec_flops"] / a["ms"] / 1e9 / peak, 4),
+                            "mfma_frac": round(a["exec_flops"] / a["ms"] / 1e9 / (a["peak"] or peak_engine), 4),
+                            "mfma_peak_tflops": a["peak"] or peak_engine,
                             "alg_GBs": round(a["bytes"] / a["ms"] / 1e6, 1),
                             "hbm_frac": round(a["bytes"] / a["ms"] / 1e6 / PEAK_HBM_GBS, 4)})
     other = {k: round(a["ms"], 3) for k, a in rows if not a["flops"]}

@@ -95,7 +95,10 @@ class SequenceDetector(BatchedDetector):
     once, when t is the current frame, and reused at step t + 1 where t is the previous frame -- exact up to nothing: the
     two stems are separate conv+BN+ReLU branches whose outputs are only summed (dla.py:260-270, :325-328); nothing
     deeper can be reused because the summed heat-map stem differs (repro_hm vs pre_hm, dla.py:1506-1507).  Saves one 7x7
-    image conv and one image read per frame pair.  fp32 engine only."""
+    image conv and one image read per frame pair on the fp32 engine.  On the 16-bit engines the stems, their sum and level0
+    are ONE kernel that reads 16 bytes per pixel and keeps the stem map on the chip: a cached 32-byte-per-pixel stem would
+    cost more than it saves, so there the step only carries the previous frame along (same interface, same results as the
+    stateless detector)."""
 
     def __init__(self, model, opt=None):
         super().__init__(model, opt)
@@ -112,7 +115,13 @@ class SequenceDetector(BatchedDetector):
         from .engine import CachedStem
         eng = self.model.engine()
         if getattr(eng, "dtype", "f32") != "f32":
-            raise ValueError("sequence mode is built for the fp32 engine")
+            if not self._have_prev:
+                if pre_image is None:
+                    raise ValueError("the first step of a sequence needs pre_image")
+                self._prev_image = pre_image
+            out = self.process_device(image, self._prev_image, pre_hm, repro_hm, pre_hm_cls, repro_hm_cls, static=static)
+            self._prev_image, self._have_prev = image, True      # self.pre_images = images (sgta_detector.py:203)
+            return out
         B, _, H, W = image.shape
         shape = (B, 16, H, W)
         for k in (0, 1):

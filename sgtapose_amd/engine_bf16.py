@@ -1,14 +1,22 @@
-"""bf16 data path of ``DLAPlanAWindowL3New.forward`` (BASELINE configs[2]; same call stack as engine.py).
+"""16-bit data path of ``DLAPlanAWindowL3New.forward`` (BASELINE configs[2]; same call stack as engine.py): bfloat16
+(``EngineBF16``) or IEEE half (``EngineF16``) feature maps and weights.
 
-Feature maps are bf16 BLOCKED CHANNELS-LAST [N,C/16,H,W,16] in HBM (half the bytes of the fp32 path; the MFMA operand of a
+Feature maps are 16-bit BLOCKED CHANNELS-LAST [N,C/16,H,W,16] in HBM (half the bytes of the fp32 path; the MFMA operand of a
 pixel and a deformable-sampling corner are contiguous 16-byte runs, and a 16-channel chunk of a window row is one
-contiguous run of memory for the LDS-DMA); weights are bf16;
-every product runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (direct-form convs: at the bf16 matrix rate the
-path is memory-bound, so Winograd is neither needed nor numerically wise).  fp32 stays where the reference's
-numerics are fragile or the data are tiny: the boundary inputs and the two 7x7 stems that read them, the DCN
-offset / mask maps and sampling arithmetic, the whole windowed attention stage (a few hundred token rows: QKV / softmax
-/ LayerNorm / FFN / cat-MLP run in the fp32 token kernels, tokens are converted at the gather / scatter), the head
-outputs and the decode.  The API boundary (inputs, output dict, decode dictionary) is unchanged.
+contiguous run of memory for the LDS-DMA); weights are 16-bit; every product runs on v_mfma_f32_32x32x16_{bf16,f16} with
+fp32 accumulation (direct-form convs: at this matrix rate the path is memory-bound, so Winograd is neither needed nor
+numerically wise).  What is rounded where (the numerics contract of this path):
+
+* the boundary inputs (fp32 NCHW images and prior maps) are rounded ONCE to the 16-bit format inside the fused stem kernel
+  (``fuse_stem``, the default: both 7x7 stems, their sum and level0 on the 16-bit MFMA, the stem map rounded in LDS); with
+  ``fuse_stem = False`` the stems run on the f32 matrix pipe from the fp32 inputs and only their sum is rounded;
+* every feature map between kernels is 16-bit; residual adds, bias, ReLU happen in fp32 on the accumulator before the store;
+* the DCN offset / mask maps and the sampling coordinates / weights are fp32; the bilinear blend itself runs in PACKED
+  fp16 (the staged window is converted to fp16 -- exact for bf16 values in range --, corner weights rounded to fp16, three
+  fp16 fma roundings) and the main product on the fp16 MFMA with fp16 weights, in both engines;
+* the whole windowed attention stage (a few hundred token rows: QKV / softmax / LayerNorm / FFN / cat-MLP) is fp32: tokens are
+  converted at the gather / scatter; the head outputs and the decode are fp32.
+The API boundary (inputs, output dict, decode dictionary) is unchanged.
 """
 import torch
 
@@ -90,6 +98,15 @@ class EngineBF16(Engine):
     split_levels = (2, 3, 4, 5)   # backbone levels run as ``split_parts`` slices of the batch on as many streams: a level is a
     split_parts = 2               # chain of launches with 1.2-round tails and latency-bound prologues; independent slices
     #                               side by side fill those gaps (measured: -3 % on the step)
+
+    def forward(self, x, *args, **kw):
+        # the kernels address a tensor with 31-bit byte offsets: the largest map (level0, 2B images x 16 channels) bounds
+        # the batch of one launch
+        B, _, H, W = x.shape
+        if 2 * B * H * W * 16 * 2 >= 2 ** 31:
+            raise ValueError("16-bit engine: batch %d at %dx%d exceeds the 2 GiB per-tensor addressing of its kernels "
+                             "(max batch %d at this size): split the batch" % (B, H, W, (2 ** 31 - 1) // (64 * H * W)))
+        return super().forward(x, *args, **kw)
 
     def hbuf(self, name, n, h, w, c, dtype=None):
         """16-bit maps: blocked [n, c/16, h, w, 16]; fp32 maps (DCN offsets): plain channels-last [n, h, w, c]."""

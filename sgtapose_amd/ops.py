@@ -554,12 +554,17 @@ def linear(x, w, bias, out, relu=False, res=None, ln=None, K=None):
         # few-hundred-token products (cat_layer of levels 3-5): split-K over work-groups, see sgta_linear_ws_f32
         nws = min(32 * M * N, 4 << 20)
         ws = _splitk_ws(x.device, nws)
+    meta = None
+    if _lib.PROFILE is not None:           # token kernels always run on the f32 matrix pipe, whatever the engine's dtype
+        meta = {"kernel": "linear_kernel (token GEMMs, f32)", "flops": 2.0 * M * N * K, "exec_flops": 2.0 * M * N * K,
+                "bytes": 4.0 * (M * K + N * K + M * N), "peak_tflops": F32_MFMA_PEAK_TFLOPS}
     _lib.call("sgta_linear_ws_f32", x.data_ptr(), x.stride(0), w.data_ptr(),
               None if bias is None else bias.data_ptr(), rp, ldr, g, bt, out.data_ptr(), out.stride(0),
-              M, N, K, int(relu), None if ws is None else ws.data_ptr(), nws, _stream())
+              M, N, K, int(relu), None if ws is None else ws.data_ptr(), nws, _stream(), meta=meta)
     return out
 
 
+F32_MFMA_PEAK_TFLOPS = 157.3    # f32-input MFMA peak of one MI355X (bench.py's roofline denominators)
 USE_FUSED_FFN = True            # encoder feed-forward block in one kernel (False: two linear launches, tests)
 
 
@@ -573,18 +578,33 @@ def ffn_ln(x, w1, b1, w2, b2, ln, out):
           and all(t.data_ptr() % 16 == 0 for t in (x, out, w1, b1, w2, b2, ln[0], ln[1])))
     if not ok:
         return None
+    meta = None
+    if _lib.PROFILE is not None:
+        meta = {"kernel": "ffn_ln_kernel (encoder FFN, f32)", "flops": 4.0 * M * C * F, "exec_flops": 4.0 * M * C * F,
+                "bytes": 4.0 * (2 * M * C + 2 * C * F), "peak_tflops": F32_MFMA_PEAK_TFLOPS}
     _lib.call("sgta_ffn_ln_f32", x.data_ptr(), x.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-              ln[0].data_ptr(), ln[1].data_ptr(), out.data_ptr(), out.stride(0), M, C, F, _stream())
+              ln[0].data_ptr(), ln[1].data_ptr(), out.data_ptr(), out.stride(0), M, C, F, _stream(), meta=meta)
     return out
 
 
 def mhca(q, k, v, pos, out, B, n, n_heads, head_dim):
     """q/k/v/out: 2-D [B*n, ld] row-major views (column slices allowed).  ``pos``: [n_heads, n, n] bias, a ``PosTiles``
     (the same bias re-packed by ``pack_pos_tiles``), or None."""
+    meta = None
+    if _lib.PROFILE is not None:
+        # algorithmic: QK^T and PV, 2 n^2 d each per (sample, head).  Issued to the matrix pipe: QK^T over 16-padded token
+        # tiles (k = head_dim, fully used) and, for head_dim >= 8, PV as 16-row MFMAs of which head_dim rows are used;
+        # head_dim 4 does PV on the VALU.  bytes: the bias stream (4 B per (head, query, key)) + q, k, v, out.
+        n16 = -(-n // 16) * 16
+        meta = {"kernel": "mhca_kernel<head_dim %d> (windowed attention, f32)" % head_dim,
+                "flops": 4.0 * B * n_heads * n * n * head_dim,
+                "exec_flops": 2.0 * B * n_heads * n16 * n16 * (head_dim + (16 if head_dim >= 8 else 0)),
+                "bytes": 4.0 * B * n_heads * (n * n + 4 * n * head_dim), "peak_tflops": F32_MFMA_PEAK_TFLOPS}
     if isinstance(pos, PosTiles):
         assert pos.n == n and pos.tiles.shape[0] == n_heads
         _lib.call("sgta_mhca_tiled_fwd_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
-                  v.stride(0), pos.tiles.data_ptr(), out.data_ptr(), out.stride(0), B, n, n_heads, head_dim, _stream())
+                  v.stride(0), pos.tiles.data_ptr(), out.data_ptr(), out.stride(0), B, n, n_heads, head_dim, _stream(),
+                  meta=meta)
         return out
     _lib.call("sgta_mhca_fwd_f32", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
               v.stride(0), None if pos is None else pos.data_ptr(), out.data_ptr(), out.stride(0), B, n,

@@ -63,19 +63,39 @@ def test_shard_bounds_cover_batch_exactly():
         shard_bounds(8, 2, 2)
 
 
-def test_bench_self_launches_ranks_and_gathers(tmp_path):
-    """``python bench.py --gpus 2`` (no torchrun): the parent spawns the ranks, rank 0 prints ONE JSON line, exit code 0.
-    --dry-run keeps it on the CPU (gloo) -- the launcher, rendezvous and all-gather flow are those of the GPU run."""
+@pytest.mark.parametrize("n,extra", [(2, []), (2, ["--dtype", "bf16"]), (2, ["--dtype", "f16"]),
+                                     (4, ["--arch", "dlapawdT_34", "--frames", "4"])])
+def test_bench_self_launches_ranks_and_gathers(n, extra):
+    """``python bench.py --gpus N`` (no torchrun) for the configurations that run multi-GPU (configs[2]: bf16 shards;
+    configs[4]: T = 4 windows over 4 ranks): the parent -- which makes no GPU call -- spawns the ranks, rank 0 prints ONE
+    JSON line, every rank holds the same gathered key-points, exit code 0.  --dry-run keeps it on the CPU (gloo) -- the
+    launcher, rendezvous and all-gather flow are those of the GPU run."""
     import json
-    import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run", "--batch", "3",
-                        "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--dry-run", "--batch", "3",
+                        "--steps", "2", "--warmup", "1"] + extra, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["ranks_seen"] == 2 and rec["n_gpus"] == 2 and rec["gather_ok"] is True
+    assert rec["ranks_seen"] == n and rec["n_gpus"] == n and rec["gather_ok"] is True
+    assert rec["gathered_keypoints_equal_on_all_ranks"] is True
+
+
+def test_bench_under_the_torch_launcher():
+    """The driver's form: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 (ranks from the launcher)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2",
+                        "--dry-run", "--batch", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2

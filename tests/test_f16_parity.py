@@ -360,3 +360,34 @@ def test_decode_of_the_16bit_paths_own_heat_maps_is_exact(dtype):
     assert np.array_equal(dets["xs"].cpu().numpy(), rd["xs"].numpy()) and np.array_equal(dets["ys"].cpu().numpy(), rd["ys"].numpy())
     assert torch.equal(dets["scores"].cpu(), rd["scores"])
     assert float((dets["cts_wreg"].cpu() - rd["cts_wreg"]).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_sequence_detector_on_the_16bit_engines_equals_the_stateless_detector(dtype):
+    from sgtapose_amd.detector import BatchedDetector, SequenceDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _f16_model()
+    m.engine_dtype = dtype
+    seq, ref = SequenceDetector(m), BatchedDetector(m)
+    frames = [make_inputs(2, 128, 160, seed=50 + i) for i in range(3)]
+    prev = frames[0]["pre_img"].to(DEV)
+    for i, f in enumerate(frames):
+        img = f["x"].to(DEV)
+        pri = [f[k].to(DEV) for k in ("pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")]
+        out_s, det_s = seq.step_device(img, *pri, pre_image=prev if i == 0 else None)
+        out_s = {k: v.clone() for k, v in out_s.items()}
+        kp_s = det_s["kp"].clone()
+        out_r, det_r = ref.process_device(img, prev, *pri)
+        for k in out_r:
+            assert torch.equal(out_s[k], out_r[k]), (i, k)
+        assert torch.equal(kp_s, det_r["kp"])
+        prev = img
+    with pytest.raises(ValueError):
+        SequenceDetector(m).step_device(img, *pri)
+
+
+def test_16bit_engine_names_its_batch_limit():
+    m = _f16_model()
+    big = torch.empty((120, 3, 480, 640), device="meta")
+    with pytest.raises(ValueError, match="max batch"):
+        m.engine().forward(big, big, None, None, None, None)
