@@ -38,8 +38,9 @@ ARGS = ("x", "pre_img", "pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")
 PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD at 2.4 GHz
 PEAK_TFLOPS_BF16_MFMA = 2500.0      # dense bf16 MFMA (the guide's ~2.5 PF; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0               # HBM3E spec
-PMC_TABLES = {"f32": os.path.join(REPO, "profiles", "r02_pmc_step_by_kernel.csv"),
-              "bf16": os.path.join(REPO, "profiles", "r02_pmc_step_by_kernel_bf16.csv")}
+PMC_TABLES = {"f32": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel.csv"),
+              "bf16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_bf16.csv"),
+              "f16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_f16.csv")}
 
 
 def log(*a):
