@@ -442,6 +442,35 @@ int sgta_window_gather_f16(const void* feats, long feats_bs, const long long* fi
 int sgta_window_scatter_f16(const float* tok, int ldt, const long long* fid, const unsigned char* win,
                             void* feats, long feats_bs, int B, int C, int H, int W, int n, sgta_stream_t stream);
 
+/* ---- fp32 emulated on the 16-bit matrix pipe by operand splitting ("x3") ------------------------------------------------------
+ * Activations are TWO IEEE-half planes of the blocked layout above, value = hi + lo with hi = half(value), lo = half(value -
+ * hi) (22 significant bits); ``*_lo_delta`` = elements from a tensor's hi plane to its lo plane (both planes in one
+ * allocation).  Weights are split the same way; every product is x_hi w_hi + x_hi w_lo + x_lo w_hi with fp32 accumulation
+ * (the dropped x_lo w_lo term is 2^-22 relative), so results agree with the fp32 operators they replace (the same reference
+ * code as sgta_conv2d_f32 / the heads) to ~1e-6 relative.  wt: sgta_conv_f16's layout over 3*Cin virtual channels -- per
+ * kc-channel chunk [w_hi, w_lo, w_hi]; Cin = the layer's real input channels. */
+int sgta_conv_x3(const void* x, long x_bytes, long x_bs, long x_lo_delta, const void* wt, long wt_bytes, const float* bias,
+                 const void* res, long res_bs, long res_lo_delta, void* y, long y_bs, long y_lo_delta, int N, int H, int W,
+                 int Cin, int Cout, int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
+                 sgta_stream_t stream);
+/* sgta_heads_f16 with split operands: w1 as sgta_conv_x3's wt, w2 / w2_lo = hi and lo parts of the second product's fragments. */
+int sgta_heads_x3(const void* x, long x_bytes, long x_bs, long x_lo_delta, const void* w1, long w1_bytes, const float* b1,
+                  const void* w2, const void* w2_lo, const float* b2, float* out0, float* out1, float* out2, float* out3,
+                  int c0, int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
+                  sgta_stream_t stream);
+/* MaxPool2d(2,2) (dla.py:218-220), window gather / ordered scatter (dla.py:915-968, :1006-1018) on x3 maps, and the hand-off
+ * between fp32 NCHW tensors and x3 maps (exact in the x3 -> fp32 direction, 22 bits kept in the other). */
+int sgta_maxpool2_x3(const void* x, long x_bs, long x_lo_delta, void* y, long y_bs, long y_lo_delta, int N, int C, int H, int W,
+                     sgta_stream_t stream);
+int sgta_window_gather_x3(const void* feats, long feats_bs, long feats_lo_delta, const long long* fid, float* tok, int B, int C,
+                          int H, int W, int n, int ld, int col0, sgta_stream_t stream);
+int sgta_window_scatter_x3(const float* tok, int ldt, const long long* fid, const unsigned char* win, void* feats, long feats_bs,
+                           long feats_lo_delta, int B, int C, int H, int W, int n, sgta_stream_t stream);
+int sgta_nchw_to_x3(const float* x, long x_bs, void* y, long y_bs, long y_lo_delta, int N, int C, int H, int W,
+                    sgta_stream_t stream);
+int sgta_x3_to_nchw(const void* x, long x_bs, long x_lo_delta, float* y, long y_bs, int N, int C, int H, int W,
+                    sgta_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,14 @@ SIGNATURES = {
     "sgta_upsample_add_f16": [_p, _l, _p, _p, _l, _p, _l, _i, _i, _i, _i, _i, _p],
     "sgta_window_gather_f16": [_p, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_window_scatter_f16": [_p, _i, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p],
+    # fp32 emulated on the 16-bit matrix pipe by operand splitting (two IEEE-half planes per activation tensor)
+    "sgta_conv_x3": [_p, _l, _l, _l, _p, _l, _p, _p, _l, _l, _p, _l, _l] + [_i] * 14 + [_p],
+    "sgta_heads_x3": [_p, _l, _l, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p] + [_i] * 12 + [_p],
+    "sgta_maxpool2_x3": [_p, _l, _l, _p, _l, _l, _i, _i, _i, _i, _p],
+    "sgta_window_gather_x3": [_p, _l, _l, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "sgta_window_scatter_x3": [_p, _i, _p, _p, _p, _l, _l, _i, _i, _i, _i, _i, _p],
+    "sgta_nchw_to_x3": [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p],
+    "sgta_x3_to_nchw": [_p, _l, _l, _p, _l, _i, _i, _i, _i, _p],
     "sgta_pre_process": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_pnp_batched": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "sgta_gn_refine": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],

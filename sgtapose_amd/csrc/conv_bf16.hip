@@ -33,6 +33,11 @@ struct CbArgs {
   float* out[4];                                 // f32 NCHW per head
   int hs[5];                                     // first output row of head i (hs[n_heads..4] = total)
   int single;                                    // two-stage loop with ONE LDS stage (see the kernel)
+  // X3 (fp32 emulated by operand splitting): every activation tensor is TWO planes of identical layout, value = hi + lo;
+  // the lo plane lies a fixed distance behind the hi plane in the same allocation
+  int x_lo_delta;                                // bytes from x to its lo plane
+  long res_lo_delta, y_lo_delta;                 // elements from res / y to their lo planes
+  const void* w2_lo;                             // FUSE: lo part of the second product's weights
 };
 
 template <int KS, int S, int KC, int NPF>
@@ -69,7 +74,12 @@ __device__ __forceinline__ void cb_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false>
+// X3: fp32 emulated on the 16-bit matrix pipe.  x = x_hi + x_lo and w = w_hi + w_lo (each part one 16-bit number: 2 x 11
+// significant bits on IEEE half), product = x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 (the dropped x_lo w_lo term
+// is 2^-22 relative).  For the kernel this is a convolution over 3x the chunks: virtual chunk v = 3 kc + p reads the window
+// of real chunk kc from the hi plane (p = 0, 1) or the lo plane (p = 2), and the packed weights hold [w_hi, w_lo, w_hi] per real
+// chunk (ops_x3.py); the epilogue splits the fp32 result into the two output planes.
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   static_assert(!P3 || (KS == 3 && KC == 16), "the three-deep pipeline is built for 3x3 convolutions");
   using G = CbGeom<KS, S, KC, NPF>;
@@ -137,6 +147,12 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), (short)0, (int)a.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), (short)0, (int)a.wt_bytes, 0x00020000);
 #endif
+  // byte offset (scalar) of the window source of (virtual) chunk v relative to a.x
+  auto src_off = [&](int v) -> int {
+    if (!X3) return v * (KC / 16) * a.H * a.W * 32;
+    const int rk = v / 3, pp3 = v - 3 * rk;
+    return rk * (KC / 16) * a.H * a.W * 32 + (pp3 == 2 ? a.x_lo_delta : 0);
+  };
   // DMA instruction j (0 .. NDMA-1) of chunk kc (weight image wi) into stage st: window rounds first, then the weight image
   constexpr int NDMA = G::WROUNDS + AROUNDS;
   auto dma_one = [&](int j, int kc, int wi, int st) {
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
     unsigned char* wdst = smem + st * STAGE + wave * 1024;
     if (j < G::WROUNDS)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + j * 8192), 16, woff[j < G::WROUNDS ? j : 0],
-                                               kc * (KC / 16) * a.H * a.W * 32, 0, 0);
+                                               src_off(kc), 0, 0);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wdst + G::WIN_BYTES + (j - G::WROUNDS) * 8192), 16,
                                                aoffw[j >= G::WROUNDS ? j - G::WROUNDS : 0], wi * WIMG, 0, 0);
@@ -213,6 +229,16 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
           f32x8 hv;
 #pragma unroll
           for (int j = 0; j < 8; ++j) hv[j] = fmaxf(acc[i][f][8 * t + j] + (j < 4 ? b0[j & 3] : b1[j & 3]), 0.0f);
+          if (X3) {
+            const bf16x8 a2l = (reinterpret_cast<const bf16x8*>(a.w2_lo) + (long)ctl * NA * 2 * 64 + lane)[(i * 2 + t) * 64];
+            const bf16x8 hh = E::cvt8(hv);
+            f32x8 hl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hl[j] = hv[j] - (float)hh[j];
+            acc2[FUSE ? f : 0] = E::mfma32(a2, hh, acc2[FUSE ? f : 0]);
+            acc2[FUSE ? f : 0] = E::mfma32(a2l, hh, acc2[FUSE ? f : 0]);
+            acc2[FUSE ? f : 0] = E::mfma32(a2, E::cvt8(hl), acc2[FUSE ? f : 0]);
+          } else
           acc2[FUSE ? f : 0] = E::mfma32(a2, E::cvt8(hv), acc2[FUSE ? f : 0]);
         }
       }
@@ -240,7 +266,7 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
 #pragma unroll
       for (int j = 0; j < WRN; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(win0 + slot * G::WIN_BYTES + wave * 1024 + j * 8192), 16, woff[j],
-                                                 kcn * a.H * a.W * 32, 0, 0);
+                                                 src_off(kcn), 0, 0);
 #endif
     };
     auto dma_wts = [&](int row, int slot) {               // row = global tap-row index: (weight image index) * 3 + tap row
@@ -378,6 +404,12 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
                                                            (long)prem[f] * 16 + (co0 & 15));
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        if (X3) {
+          const bf16x4 rl = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const elt*>(a.res) + a.res_lo_delta + (long)pn[f] * a.res_bs +
+                                                             (long)(co0 >> 4) * HWo * 16 + (long)prem[f] * 16 + (co0 & 15));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rl[j];
+        }
       }
       if (a.act == 1) {
 #pragma unroll
@@ -400,15 +432,25 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const bf16x4 pb = E::cvt4(value4(i, f, 2 * m));
-          const bf16x4 qb = E::cvt4(value4(i, f, 2 * m + 1));
+          const f32x4 pv = value4(i, f, 2 * m), qv = value4(i, f, 2 * m + 1);
+          const bf16x4 pb = E::cvt4(pv);
+          const bf16x4 qb = E::cvt4(qv);
           const u32x2 P = __builtin_bit_cast(u32x2, pb), Q = __builtin_bit_cast(u32x2, qb);
           const auto s0 = __builtin_amdgcn_permlane32_swap(P[0], Q[0], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(P[1], Q[1], false, false);
           const int co = ct * TC + i * 32 + 16 * m + 8 * h;
+          elt* const yp = reinterpret_cast<elt*>(a.y) + (long)pn[f] * a.y_bs + (long)(co >> 4) * HWo * 16 + (long)prem[f] * 16 + (co & 15);
           if (co < a.Cout)                       // blocked: block co >> 4, the lane's half (8 h) of the pixel's 16-channel run
-            *reinterpret_cast<u32x4*>(reinterpret_cast<elt*>(a.y) + (long)pn[f] * a.y_bs + (long)(co >> 4) * HWo * 16 +
-                                      (long)prem[f] * 16 + (co & 15)) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            *reinterpret_cast<u32x4*>(yp) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          if (X3) {                              // the lo plane: what the hi plane's rounding left over
+            f32x4 pl, ql;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pl[j] = pv[j] - (float)pb[j]; ql[j] = qv[j] - (float)qb[j]; }
+            const u32x2 PL = __builtin_bit_cast(u32x2, E::cvt4(pl)), QL = __builtin_bit_cast(u32x2, E::cvt4(ql));
+            const auto t0 = __builtin_amdgcn_permlane32_swap(PL[0], QL[0], false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(PL[1], QL[1], false, false);
+            if (co < a.Cout) *reinterpret_cast<u32x4*>(yp + a.y_lo_delta) = u32x4{t0[0], t1[0], t0[1], t1[1]};
+          }
         }
       continue;
     }
@@ -420,8 +462,15 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
         if (co0 >= a.Cout) continue;
         const f32x4 v = value4(i, f, g4);
         if (a.out_mode == 0) {
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<elt*>(a.y) + (long)pn[f] * a.y_bs + (long)(co0 >> 4) * HWo * 16 +
-                                     (long)prem[f] * 16 + (co0 & 15)) = E::cvt4(v);
+          elt* const yp = reinterpret_cast<elt*>(a.y) + (long)pn[f] * a.y_bs + (long)(co0 >> 4) * HWo * 16 + (long)prem[f] * 16 + (co0 & 15);
+          const bf16x4 vh = E::cvt4(v);
+          *reinterpret_cast<bf16x4*>(yp) = vh;
+          if (X3) {
+            f32x4 vl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vl[j] = v[j] - (float)vh[j];
+            *reinterpret_cast<bf16x4*>(yp + a.y_lo_delta) = E::cvt4(vl);
+          }
         } else if (a.out_mode == 2) {
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y) + pix * a.y_bs + co0) = v;
         } else {
@@ -434,14 +483,14 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   }
 }
 
-template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false>
+template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false, bool X3 = false>
 static int cb_launch(CbArgs& a, hipStream_t st) {
   using G = CbGeom<KS, S, KC, NPF>;
   constexpr int WIMG = KS * KS * NA * 32 * KC * 2;
   constexpr int LDS = P3 ? 2 * G::WIN_BYTES + 3 * ((3 * NA * 32 * KC * 2 + 8191) / 8192) * 8192
                          : 2 * (G::WIN_BYTES + ((WIMG + 8191) / 8192) * 8192);
   static_assert(LDS <= 160 * 1024, "LDS budget");
-  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE, P3, F16>;
+  auto kern = conv_bf16_kernel<KS, S, KC, NPF, NA, FUSE, P3, F16, X3>;
   static bool attr_by_dev[SGTA_MAX_DEVICES] = {};
   bool& done = attr_by_dev[sgta_device_slot()];
   if (!done) {
@@ -471,11 +520,14 @@ static int cb_launch(CbArgs& a, hipStream_t st) {
 // [N,Ho,Wo,y_bs], 1: y f32 NCHW [N,Cout,Ho,Wo] with sigmoid on channels < nsig.  act: 0 none, 1 ReLU.
 // npf: 32-position fragments per wave (2: 512-position tiles; 1: 256; stride 2 needs 1); log_tw: log2 of the tile width
 // (3..6).  Cin % kc == 0, kc in {16 (3x3), 32 (1x1)}.
-template <bool F16>
+template <bool F16, bool X3 = false>
 static int cb_conv(const void* x, long x_bytes, long x_bs, const void* wt, long wt_bytes, const float* bias,
                    const void* res, long res_bs, void* y, long y_bs, int N, int H, int W, int Cin, int Cout,
                    int ks, int stride, int kc, int na, int npf, int log_tw, int act, int out_mode, int nsig,
-                   hipStream_t st) {
+                   hipStream_t st, long x_lo_delta = 0, long res_lo_delta = 0, long y_lo_delta = 0) {
+  if (X3 && (x_lo_delta <= 0 || x_lo_delta * 2 > 0x7fffffffL || x_lo_delta % 8 || (out_mode == 0 && (y_lo_delta <= 0 || y_lo_delta % 8)) ||
+             (res && (res_lo_delta <= 0 || res_lo_delta % 4))))
+    return SGTA_EBADARG;
   if (!x || !wt || !bias || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return SGTA_EBADARG;
   if (x_bytes <= 0 || x_bytes > 0x7fffffffL || wt_bytes <= 0 || wt_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if (Cin % kc || (x_bs % 16) || ((uintptr_t)x & 15) || log_tw < 3 || log_tw > 6 || act < 0 || act > 1 || out_mode < 0 ||
@@ -488,32 +540,33 @@ static int cb_conv(const void* x, long x_bytes, long x_bs, const void* wt, long 
   a.x = x; a.x_bytes = x_bytes; a.x_bs = x_bs; a.wt = wt; a.wt_bytes = wt_bytes; a.bias = bias;
   a.res = res; a.res_bs = res_bs; a.y = y; a.y_bs = y_bs;
   a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / stride + 1; a.Wo = (W - 1) / stride + 1; a.Cout = Cout;
-  a.nchunks = Cin / kc; a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act; a.out_mode = out_mode; a.nsig = nsig;
+  a.nchunks = (X3 ? 3 : 1) * (Cin / kc); a.n_ct = cdiv(Cout, 32 * na); a.log_tw = log_tw; a.act = act; a.out_mode = out_mode; a.nsig = nsig;
+  a.x_lo_delta = (int)(x_lo_delta * 2); a.res_lo_delta = res_lo_delta; a.y_lo_delta = y_lo_delta;
   if (npf != 1 && npf != 2) return SGTA_EBADARG;
   const int TW = 1 << log_tw, TR = (256 * npf) >> log_tw;
   a.n_rt = cdiv((long)N * (a.Ho + 1), TR);
   a.n_xt = cdiv(a.Wo, TW);
   static const bool p3 = sgta_tool_env("SGTA_CONV_P3", 1) != 0;   // tools: 0 = the two-stage loop
   if (ks == 3 && stride == 1 && kc == 16 && npf == 2) {
-    if (na == 1) return p3 ? cb_launch<3, 1, 16, 2, 1, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 2, 1, 0, false, F16>(a, st);
-    if (na == 2) return p3 ? cb_launch<3, 1, 16, 2, 2, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 2, 2, 0, false, F16>(a, st);
-    if (na == 4) return p3 ? cb_launch<3, 1, 16, 2, 4, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 2, 4, 0, false, F16>(a, st);
+    if (na == 1) return p3 ? cb_launch<3, 1, 16, 2, 1, 0, true, F16, X3>(a, st) : cb_launch<3, 1, 16, 2, 1, 0, false, F16, X3>(a, st);
+    if (na == 2) return p3 ? cb_launch<3, 1, 16, 2, 2, 0, true, F16, X3>(a, st) : cb_launch<3, 1, 16, 2, 2, 0, false, F16, X3>(a, st);
+    if (na == 4) return p3 ? cb_launch<3, 1, 16, 2, 4, 0, true, F16, X3>(a, st) : cb_launch<3, 1, 16, 2, 4, 0, false, F16, X3>(a, st);
   } else if (ks == 3 && stride == 1 && kc == 16 && npf == 1) {       // half-size tiles: small maps (work-group count / tail)
-    if (na == 1) return p3 ? cb_launch<3, 1, 16, 1, 1, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 1, 1, 0, false, F16>(a, st);
-    if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 1, 2, 0, false, F16>(a, st);
-    if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true, F16>(a, st) : cb_launch<3, 1, 16, 1, 4, 0, false, F16>(a, st);
+    if (na == 1) return p3 ? cb_launch<3, 1, 16, 1, 1, 0, true, F16, X3>(a, st) : cb_launch<3, 1, 16, 1, 1, 0, false, F16, X3>(a, st);
+    if (na == 2) return p3 ? cb_launch<3, 1, 16, 1, 2, 0, true, F16, X3>(a, st) : cb_launch<3, 1, 16, 1, 2, 0, false, F16, X3>(a, st);
+    if (na == 4) return p3 ? cb_launch<3, 1, 16, 1, 4, 0, true, F16, X3>(a, st) : cb_launch<3, 1, 16, 1, 4, 0, false, F16, X3>(a, st);
   } else if (ks == 3 && stride == 2 && kc == 16 && npf == 1) {
     static const bool p3s2 = sgta_tool_env("SGTA_CONV_P3S2", 0) == 1;
-    if (na == 1) return p3s2 ? cb_launch<3, 2, 16, 1, 1, 0, true, F16>(a, st) : cb_launch<3, 2, 16, 1, 1, 0, false, F16>(a, st);
-    if (na == 2) return p3s2 ? cb_launch<3, 2, 16, 1, 2, 0, true, F16>(a, st) : cb_launch<3, 2, 16, 1, 2, 0, false, F16>(a, st);
+    if (na == 1) return p3s2 ? cb_launch<3, 2, 16, 1, 1, 0, true, F16, X3>(a, st) : cb_launch<3, 2, 16, 1, 1, 0, false, F16, X3>(a, st);
+    if (na == 2) return p3s2 ? cb_launch<3, 2, 16, 1, 2, 0, true, F16, X3>(a, st) : cb_launch<3, 2, 16, 1, 2, 0, false, F16, X3>(a, st);
   } else if (ks == 1 && stride == 1 && kc == 32 && npf == 2) {
-    if (na == 1) return cb_launch<1, 1, 32, 2, 1, 0, false, F16>(a, st);
-    if (na == 2) return cb_launch<1, 1, 32, 2, 2, 0, false, F16>(a, st);
-    if (na == 4) return cb_launch<1, 1, 32, 2, 4, 0, false, F16>(a, st);
+    if (na == 1) return cb_launch<1, 1, 32, 2, 1, 0, false, F16, X3>(a, st);
+    if (na == 2) return cb_launch<1, 1, 32, 2, 2, 0, false, F16, X3>(a, st);
+    if (na == 4) return cb_launch<1, 1, 32, 2, 4, 0, false, F16, X3>(a, st);
   } else if (ks == 1 && stride == 1 && kc == 32 && npf == 1) {
-    if (na == 1) return cb_launch<1, 1, 32, 1, 1, 0, false, F16>(a, st);
-    if (na == 2) return cb_launch<1, 1, 32, 1, 2, 0, false, F16>(a, st);
-    if (na == 4) return cb_launch<1, 1, 32, 1, 4, 0, false, F16>(a, st);
+    if (na == 1) return cb_launch<1, 1, 32, 1, 1, 0, false, F16, X3>(a, st);
+    if (na == 2) return cb_launch<1, 1, 32, 1, 2, 0, false, F16, X3>(a, st);
+    if (na == 4) return cb_launch<1, 1, 32, 1, 4, 0, false, F16, X3>(a, st);
   }
   return SGTA_EBADARG;
 }
@@ -541,11 +594,12 @@ extern "C" int sgta_conv_f16(const void* x, long x_bytes, long x_bs, const void*
 // sigmoid on rows < nsig.  w2: bf16 A fragments [Chid/128][4][2][64 lanes][8] of the second v_mfma_f32_32x32x16_bf16: lane
 // (m = lane & 31, h = lane >> 5), element j of k-step t of 32-channel block i holds W2[m][128 ct + 32 i + 8 (2t + (j >> 2)) +
 // 4h + (j & 3)] (zero for m >= the number of rows).  npf / log_tw as sgta_conv_bf16.  Cin % 16 == 0, Chid % 128 == 0.
-template <bool F16>
+template <bool F16, bool X3 = false>
 static int cb_heads(const void* x, long x_bytes, long x_bs, const void* w1, long w1_bytes, const float* b1,
                     const void* w2, const float* b2, float* out0, float* out1, float* out2, float* out3, int c0,
                     int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf, int log_tw, int nsig,
-                    hipStream_t st) {
+                    hipStream_t st, long x_lo_delta = 0, const void* w2_lo = nullptr) {
+  if (X3 && (x_lo_delta <= 0 || x_lo_delta * 2 > 0x7fffffffL || x_lo_delta % 8 || !w2_lo || ((uintptr_t)w2_lo & 15))) return SGTA_EBADARG;
   if (!x || !w1 || !b1 || !w2 || !b2 || !out0 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Chid <= 0) return SGTA_EBADARG;
   if (x_bytes <= 0 || x_bytes > 0x7fffffffL || w1_bytes <= 0 || w1_bytes > 0x7fffffffL) return SGTA_EBADARG;
   if (Cin % 16 || Chid % 128 || (x_bs % 16) || ((uintptr_t)x & 15) || ((uintptr_t)w2 & 15) || log_tw < 3 || log_tw > 6) return SGTA_EBADARG;
@@ -553,7 +607,8 @@ static int cb_heads(const void* x, long x_bytes, long x_bs, const void* w1, long
   if ((c1 > 0 && !out1) || (c2 > 0 && !out2) || (c3 > 0 && !out3)) return SGTA_EBADARG;
   CbArgs a{};
   a.x = x; a.x_bytes = x_bytes; a.x_bs = x_bs; a.wt = w1; a.wt_bytes = w1_bytes; a.bias = b1;
-  a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = Chid; a.nchunks = Cin / 16; a.n_ct = Chid / 128;
+  a.N = N; a.H = H; a.W = W; a.Ho = H; a.Wo = W; a.Cout = Chid; a.nchunks = (X3 ? 3 : 1) * (Cin / 16); a.n_ct = Chid / 128;
+  a.x_lo_delta = (int)(x_lo_delta * 2); a.w2_lo = w2_lo;
   a.log_tw = log_tw; a.act = 1; a.out_mode = 1; a.nsig = nsig;
   a.w2 = w2; a.b2 = b2; a.out[0] = out0; a.out[1] = out1; a.out[2] = out2; a.out[3] = out3;
   a.hs[0] = 0; a.hs[1] = c0; a.hs[2] = c0 + c1; a.hs[3] = c0 + c1 + c2; a.hs[4] = c0 + c1 + c2 + c3;
@@ -562,8 +617,8 @@ static int cb_heads(const void* x, long x_bytes, long x_bs, const void* w1, long
   a.n_xt = cdiv(W, TW);
   // (the two-stage loop: with six channel tiles per work-group and no output tensor its waits are already hidden, and the
   // three-deep form's extra barriers cost it 9 % here)
-  if (npf == 2) return cb_launch<3, 1, 16, 2, 4, 1, false, F16>(a, st);
-  if (npf == 1) return cb_launch<3, 1, 16, 1, 4, 1, false, F16>(a, st);
+  if (npf == 2) return cb_launch<3, 1, 16, 2, 4, 1, false, F16, X3>(a, st);
+  if (npf == 1) return cb_launch<3, 1, 16, 1, 4, 1, false, F16, X3>(a, st);
   return SGTA_EBADARG;
 }
 
@@ -581,4 +636,27 @@ extern "C" int sgta_heads_f16(const void* x, long x_bytes, long x_bs, const void
                               hipStream_t st) {
   return cb_heads<true>(x, x_bytes, x_bs, w1, w1_bytes, b1, w2, b2, out0, out1, out2, out3, c0, c1, c2, c3, N, H, W, Cin, Chid,
                         npf, log_tw, nsig, st);
+}
+
+// ---- fp32 emulated on the 16-bit matrix pipe by operand splitting (see the kernel's X3 note).  Same layouts as sgta_conv_f16
+// with every activation tensor in TWO IEEE-half planes of identical layout (value = hi + lo; *_lo_delta = elements from a
+// tensor's hi plane to its lo plane, both inside one allocation), Cin = the layer's real input channels, and wt packed
+// over 3 Cin virtual channels: per kc-channel chunk [w_hi, w_lo, w_hi] with w_hi = half(w), w_lo = half(w - w_hi).
+// Results agree with an fp32 convolution to ~1e-6 relative.
+extern "C" int sgta_conv_x3(const void* x, long x_bytes, long x_bs, long x_lo_delta, const void* wt, long wt_bytes, const float* bias,
+                            const void* res, long res_bs, long res_lo_delta, void* y, long y_bs, long y_lo_delta, int N, int H,
+                            int W, int Cin, int Cout, int ks, int stride, int kc, int na, int npf, int log_tw, int act,
+                            int out_mode, int nsig, hipStream_t st) {
+  return cb_conv<true, true>(x, x_bytes, x_bs, wt, wt_bytes, bias, res, res_bs, y, y_bs, N, H, W, Cin, Cout, ks, stride, kc, na, npf,
+                             log_tw, act, out_mode, nsig, st, x_lo_delta, res_lo_delta, y_lo_delta);
+}
+
+// sgta_heads_f16 with split operands: w1 over 3 Cin virtual channels as sgta_conv_x3, w2 / w2_lo = hi and lo parts of the
+// second product's fragments; the hidden activations are split in registers.
+extern "C" int sgta_heads_x3(const void* x, long x_bytes, long x_bs, long x_lo_delta, const void* w1, long w1_bytes, const float* b1,
+                             const void* w2, const void* w2_lo, const float* b2, float* out0, float* out1, float* out2,
+                             float* out3, int c0, int c1, int c2, int c3, int N, int H, int W, int Cin, int Chid, int npf,
+                             int log_tw, int nsig, hipStream_t st) {
+  return cb_heads<true, true>(x, x_bytes, x_bs, w1, w1_bytes, b1, w2, b2, out0, out1, out2, out3, c0, c1, c2, c3, N, H, W, Cin, Chid,
+                              npf, log_tw, nsig, st, x_lo_delta, w2_lo);
 }

@@ -1,0 +1,156 @@
+"""GPU (-m gpu): fp32 emulated on the 16-bit matrix pipe by operand splitting (C ABI ``sgta_*_x3``): every activation is two
+IEEE-half planes (value = hi + lo, 22 significant bits), weights are split the same way, each product is three 16-bit MFMA
+products accumulated in fp32.  Bar: agreement with torch's fp32 operator on the UNROUNDED fp32 inputs to 2e-5 of the
+output's largest magnitude (the fp32 kernels themselves sit at ~1e-6; bf16 at 1e-2, f16 at 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def xo():
+    from sgtapose_amd import _lib, ops_x3
+    _lib.load()
+    return ops_x3
+
+
+def close(got, ref, rel=2e-5):
+    err = float((got - ref).abs().max())
+    assert err <= rel * float(ref.abs().max()) + 1e-7, "max err %.3e (ref max %.3e)" % (err, float(ref.abs().max()))
+    return err
+
+
+def test_split_is_exact_to_22_bits(xo):
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn(4, 32, 6, 10, generator=g) * 3
+    v = xo.x3_from_nchw(t, DEV)
+    back = v.nchw().cpu()
+    assert float((back - t).abs().max()) <= 3e-7 * 3 * 4          # 2^-22 relative of values up to ~12
+
+
+@pytest.mark.parametrize("N,cin,cout,H,W,ks,stride,act,res", [
+    (2, 16, 16, 20, 36, 3, 1, 1, False), (1, 64, 64, 17, 23, 3, 1, 1, True), (3, 128, 256, 8, 12, 3, 1, 1, True),
+    (2, 32, 64, 16, 24, 3, 2, 1, False), (5, 256, 512, 6, 8, 3, 2, 1, False), (4, 512, 512, 15, 20, 3, 1, 1, True),
+    (2, 128, 64, 9, 13, 1, 1, 1, False), (3, 448, 128, 6, 10, 1, 1, 1, False), (1, 1280, 512, 15, 20, 1, 1, 1, False),
+    (2, 64, 32, 12, 70, 3, 1, 0, False), (2, 64, 128, 30, 40, 3, 1, 1, False),
+])
+def test_conv_x3_matches_fp32(xo, N, cin, cout, H, W, ks, stride, act, res):
+    g = torch.Generator().manual_seed(N * 1000 + cin + cout + H)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (1.5 / (cin * ks * ks) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    pc = xo.PackedConvX3(w.to(DEV), b.to(DEV), None, stride=stride)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = torch.randn(N, cout, Ho, Wo, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
+    if res:
+        ref = ref + r.double()
+    if act:
+        ref = F.relu(ref)
+    out = xo.ViewX.alloc(N, cout, Ho, Wo, DEV)
+    out.base.fill_(7.0)
+    xo.conv(xo.x3_from_nchw(x, DEV), pc, out, act, res=xo.x3_from_nchw(r, DEV) if res else None)
+    close(out.nchw().cpu().double(), ref)
+
+
+def test_conv_x3_channel_slices_fp32_outputs_and_batch_views(xo):
+    from sgtapose_amd.ops_bf16 import ViewH
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 4, 14, 22
+    big = torch.randn(N, 96, H, W, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.1
+    pc = xo.PackedConvX3(w.to(DEV), b.to(DEV))
+    xin = xo.x3_from_nchw(big, DEV)
+    outbuf = xo.ViewX.alloc(N, 160, H, W, DEV)
+    outbuf.base.zero_()
+    outbuf.lo.base.zero_()
+    # a channel slice of the input into a channel slice of the output, for the second half of the batch only
+    xo.conv(xin.slice(32, 32).images(2, 4), pc, outbuf.slice(64, 64).images(2, 4), 1)
+    ref = F.relu(F.conv2d(big[2:4, 32:64].double(), w.double(), b.double(), padding=1))
+    got = outbuf.nchw().cpu().double()
+    close(got[2:4, 64:128], ref)
+    assert float(got[:2].abs().max()) == 0 and float(got[2:, :64].abs().max()) == 0 and float(got[2:, 128:].abs().max()) == 0
+    # fp32 NHWC (the 27 -> 32 channel offset conv) and fp32 NCHW with sigmoid
+    w27 = torch.randn(27, 32, 3, 3, generator=g) * 0.1
+    b27 = torch.randn(27, generator=g) * 0.3
+    pco = xo.PackedConvX3(w27.to(DEV), b27.to(DEV), cout_pad_to=32)
+    om = torch.full((N, H, W, 32), 3.0, dtype=torch.float32, device=DEV)
+    xo.conv(xin.slice(32, 32), pco, ViewH(om), 0, out_mode=xo.OUT_F32_NHWC)
+    refo = F.conv2d(big[:, 32:64].double(), w27.double(), b27.double(), padding=1)
+    gm = om.cpu().permute(0, 3, 1, 2).double()
+    close(gm[:, :27], refo)
+    assert float(gm[:, 27:].abs().max()) == 0
+    w11 = torch.randn(11, 64, 1, 1, generator=g) * 0.2
+    b11 = torch.randn(11, generator=g)
+    pch = xo.PackedConvX3(w11.to(DEV), b11.to(DEV))
+    o = torch.empty(N, 11, H, W, device=DEV)
+    xo.conv(xin.slice(0, 64), pch, o, 0, out_mode=xo.OUT_F32_NCHW, nsig=7)
+    refh = F.conv2d(big[:, :64].double(), w11.double(), b11.double())
+    refh[:, :7] = torch.sigmoid(refh[:, :7])
+    close(o.cpu().double(), refh, rel=5e-5)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 14, 22), (1, 30, 40)])
+def test_heads_x3_matches_fp32(xo, N, H, W):
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, 64, H, W, generator=g)
+    heads, ref = [], []
+    for n in (7, 2, 2):
+        w3 = torch.randn(256, 64, 3, 3, generator=g) * 0.06
+        b3 = torch.randn(256, generator=g) * 0.1
+        w1 = torch.randn(n, 256, 1, 1, generator=g) * 0.1
+        b1 = torch.randn(n, generator=g)
+        heads.append(tuple(t.to(DEV) for t in (w3, b3, w1, b1)))
+        hid = F.relu(F.conv2d(x.double(), w3.double(), b3.double(), padding=1))
+        ref.append(F.conv2d(hid, w1.double(), b1.double()))
+    ref[0] = torch.sigmoid(ref[0])
+    pk = xo.PackedHeadsX3(heads)
+    outs = [torch.full((N, n, H, W), 5.0, device=DEV) for n in (7, 2, 2)]
+    xo.heads_fused(xo.x3_from_nchw(x, DEV), pk, outs, nsig=7)
+    for o, r in zip(outs, ref):
+        close(o.cpu().double(), r, rel=5e-5)
+
+
+def test_elementwise_x3(xo):
+    from sgtapose_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 32, 10, 14, generator=g)
+    xv = xo.x3_from_nchw(x, DEV)
+    x22 = xv.nchw().cpu()                                   # the 22-bit values the planes hold
+    out = xo.ViewX.alloc(3, 64, 5, 7, DEV)
+    out.base.zero_()
+    out.lo.base.zero_()
+    xo.maxpool2(xv, out.slice(16, 32))
+    got = out.nchw().cpu()
+    assert torch.equal(got[:, 16:48], F.max_pool2d(x22, 2))
+    assert float(got[:, :16].abs().max()) == 0 and float(got[:, 48:].abs().max()) == 0
+    B, C, H, W, n = 3, 32, 10, 14, 20
+    fid = torch.randint(0, H * W, (B, n), generator=g)
+    fid[0, 5] = fid[0, 2]
+    win = torch.ones(B, n, dtype=torch.uint8)
+    for b in range(B):
+        for t_ in range(n):
+            win[b, t_] = int(not bool((fid[b, t_ + 1:] == fid[b, t_]).any()))
+    tok = torch.zeros(B * n, 40, device=DEV)
+    xo.window_gather(xv, fid.to(DEV), tok, col0=8)
+    ref = torch.gather(x22.reshape(B, C, -1), 2, fid.view(B, 1, n).expand(B, C, n)).permute(0, 2, 1).reshape(B * n, C)
+    assert torch.equal(tok[:, 8:].cpu(), ref) and float(tok[:, :8].abs().max()) == 0
+    new = torch.randn(B * n, C, generator=g)
+    xo.window_scatter(new.to(DEV), fid.to(DEV), win.to(DEV), xv)
+    want = x22.reshape(B, C, -1).clone()
+    for b in range(B):
+        for t in range(n):
+            want[b, :, fid[b, t]] = new[b * n + t]
+    assert float((xv.nchw().cpu().reshape(B, C, -1) - want).abs().max()) <= 2e-6
+    # fp32 NCHW <-> x3 (a channel slice of a wider fp32 buffer in, exact on the way back)
+    wide = torch.randn(3, 48, 10, 14, generator=g).to(DEV)
+    xv2 = xo.ViewX.alloc(3, 32, 10, 14, DEV)
+    xo.from_nchw(ops.View(wide, 16, 32), xv2)
+    assert float((xv2.nchw() - wide[:, 16:48]).abs().max()) <= 2e-6
+    back = torch.zeros(3, 48, 10, 14, device=DEV)
+    xo.to_nchw(xv2, ops.View(back, 16, 32))
+    assert torch.equal(back[:, 16:48], xv2.nchw()) and float(back[:, :16].abs().max()) == 0
