@@ -184,6 +184,7 @@ def _median(v):
 # tolerances on the logits (tests/test_bf16_parity.py, tests/test_f16_parity.py) -- a 16-bit run is never held to, or
 # reported against, the fp32 bar
 PARITY_BARS = {"f32": {"max_abs": 1e-3, "text": "1e-3 abs on hm / reg / tracking (north_star)"},
+               "f32x3": {"max_abs": 1e-3, "text": "1e-3 abs on hm / reg / tracking (north_star): the fp32 bar, fp32 emulated by operand splitting"},
                "f16": {"max_abs": 1.2e-2, "text": "stated f16 tolerance: 1.2e-2 abs on reg / tracking and on the hm logits"},
                "bf16": {"max_abs": 6e-2, "text": "stated bf16 tolerance: 6e-2 abs on reg / tracking and on the hm logits"}}
 
@@ -255,7 +256,7 @@ def batch_parity(refs, hip_out, hip_dets, dtype):
                         np.array_equal(hip_dets["ys"][i].cpu().numpy(), d["ys"][0]))
         if f.any():
             l2 = max(l2, float(np.sqrt(((kp_hip[f, :2] - kp_ref[f, :2]) ** 2).sum(1)).max()))
-    worst = max(err["hm"] if dtype == "f32" else err["hm_logit"], err["reg"], err["tracking"])
+    worst = max(err["hm"] if dtype in ("f32", "f32x3") else err["hm_logit"], err["reg"], err["tracking"])
     return {"samples_of_benched_batch": sorted(refs), "hm_max_abs": err["hm"], "hm_logit_max_abs": err["hm_logit"],
             "reg_max_abs": err["reg"], "tracking_max_abs": err["tracking"], "keypoints_found_ref": found_ref,
             "found_masks_identical": found_same == len(refs),
@@ -344,7 +345,8 @@ def dry_run(args):
 def roofline_record(local_step, dtype, wl, el_ms, breakdown=False):
     """Per-kernel durations of a LOCAL (collective-free) instrumented pass -> (roofline of the dominant kernel, per-kernel
     list, kernels without a FLOP / byte model)."""
-    peak = PEAK_TFLOPS_F32_MFMA if dtype == "f32" else PEAK_TFLOPS_BF16_MFMA      # fp16 and bf16 MFMA run at the same rate
+    # fp16 and bf16 MFMA run at the same rate; the hybrid f32x3 engine's fp32 kernels carry their own peak in their meta
+    peak = PEAK_TFLOPS_F32_MFMA if dtype in ("f32", "f32x3") else PEAK_TFLOPS_BF16_MFMA
     agg = instrumented_pass(local_step, 2)
     tot = sum(a["ms"] for a in agg.values())
     rows = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
@@ -418,10 +420,11 @@ def main():
                     help="dlapawd3_34 = the reference's three-frame variant (frame triples/s); dlapawdT_34 = its generalisation "
                          "to a window of --frames frames (BASELINE configs[4]: --frames 4); neither is the headline metric")
     ap.add_argument("--frames", type=int, default=4, help="temporal window length of dlapawdT_34 (previous frames + current)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16", "f32x3"],
                     help="f32 = BASELINE configs[1] (the headline); bf16 = configs[2]'s data path (bf16 feature maps / "
                          "weights on bf16 MFMA, fp32 accumulate / softmax / LayerNorm / decode); f16 = the same data path "
-                         "on IEEE half (an eighth of bf16's rounding error, same speed)")
+                         "on IEEE half (an eighth of bf16's rounding error, same speed); f32x3 = fp32 ACCURACY with the backbone "
+                         "/ head convolutions emulated on the 16-bit matrix pipe by operand splitting (engine_x3.py)")
     ap.add_argument("--secondary", default=None,
                     help="comma list of further compute dtypes timed in the same process after the primary one and reported "
                          "under 'secondary' (default: bf16,f16 for the default single-GPU fp32 two-frame workload, else none)")
@@ -532,6 +535,7 @@ def main():
     unit_name = ("frame-windows(T=%d)" % args.frames) if seq else ("frame-triples" if three else "frame-pairs")
     cfg_name = {(32, 480, 640, "f32"): "configs[1]", (32, 480, 640, "bf16"): "configs[2] per-GPU shard (32 pairs, bf16)",
                 (32, 480, 640, "f16"): "configs[2] per-GPU shard on IEEE half (32 pairs, f16)",
+                (32, 480, 640, "f32x3"): "configs[1] at fp32 accuracy, convolutions emulated on the 16-bit matrix pipe (f32x3)",
                 (16, 736, 1280, "f32"): "configs[3] (720p padded to a multiple of 32)"}.get((B, H, W, args.dtype), "custom")
     if three:
         cfg_name = "three-frame variant dlapawd3_34 (seq_len 3: the reference's widest; towards configs[4])"
@@ -585,7 +589,7 @@ def main():
         prefs = peaked_reference(inp, picks)
         cb["parity"]["peaked_weights"] = peaked_parity(dev, inp, prefs, args.dtype)
         result["cpu_baseline"] = cb
-        result["parity_ok"] = bool(cb["parity"]["within_bar"] and (args.dtype != "f32" or (
+        result["parity_ok"] = bool(cb["parity"]["within_bar"] and (args.dtype not in ("f32", "f32x3") or (
             cb["parity"]["integer_peaks_identical"] and cb["parity"]["peaked_weights"]["integer_peaks_identical"])))
 
     # ---- further compute dtypes of the SAME workload, timed in this process with the same K / W and bracket ---------------

@@ -236,21 +236,25 @@ class DLAPlanAWindowL3New(nn.Module):
 
     # 'f32' (the reference's arithmetic, BASELINE configs[1]), 'bf16' (configs[2]: bf16 feature maps / weights on bf16
     # MFMA, fp32 accumulate / softmax / LayerNorm / decode) or 'f16' (the same data path on IEEE half: an eighth of bf16's
-    # rounding error at the same speed, range +-65504); also read from opt.compute_dtype at construction
+    # rounding error at the same speed, range +-65504) or 'f32x3' (fp32 ACCURACY with the backbone / head convolutions
+    # emulated on the 16-bit matrix pipe by operand splitting, engine_x3.py); also read from opt.compute_dtype at construction
     @property
     def engine_dtype(self):
         return getattr(self, "_engine_dtype", getattr(self.opt, "compute_dtype", "f32"))
 
     @engine_dtype.setter
     def engine_dtype(self, v):
-        if v not in ("f32", "bf16", "f16"):
-            raise ValueError("engine_dtype must be 'f32', 'bf16' or 'f16'")
+        if v not in ("f32", "bf16", "f16", "f32x3"):
+            raise ValueError("engine_dtype must be 'f32', 'bf16', 'f16' or 'f32x3'")
         object.__setattr__(self, "_engine_dtype", v)
         self._engine = None
 
     def engine(self):
         if self._engine is None:
-            if self.engine_dtype in ("bf16", "f16"):
+            if self.engine_dtype == "f32x3":          # fp32 accuracy, convolutions emulated on the 16-bit matrix pipe
+                from ..engine_x3 import EngineX3
+                self._engine = EngineX3(self)
+            elif self.engine_dtype in ("bf16", "f16"):
                 from ..engine_bf16 import EngineBF16, EngineF16
                 self._engine = (EngineF16 if self.engine_dtype == "f16" else EngineBF16)(self)
             else:

@@ -116,7 +116,7 @@ def conv(x, pc, out, act=ACT_NONE, res=None, out_mode=OUT_X3_BLOCKED, nsig=0):
     if _lib.PROFILE is not None:
         M = x.N * Ho * Wo
         meta = {"kernel": "conv_x3_kernel<%d,%d,%d>" % (pc.ks, pc.stride, pc.na), "flops": pc.flops(M),
-                "exec_flops": 3.0 * pc.flops(M),
+                "exec_flops": 3.0 * pc.flops(M), "peak_tflops": 2500.0,
                 "bytes": 4.0 * (pc.Cin_real * x.N * x.H * x.W + pc.Cout * pc.Cin_real * pc.ks ** 2) + 4.0 * cout * M}
     npf = pc.tile_npf(x.N, Ho, Wo)
     _lib.call("sgta_conv_x3", x.ptr, x.nbytes, x.bs, x.lo_delta, pc.wt.data_ptr(), pc.wt.numel() * 2, pc.bias.data_ptr(),
@@ -169,7 +169,7 @@ def heads_fused(x, pk, outs, nsig=0):
     if _lib.PROFILE is not None:
         M = x.N * x.H * x.W
         fl = pk.pc1.flops(M) + 2.0 * M * pk.Chid * sum(pk.rows)
-        meta = {"kernel": "conv_x3_kernel<3,1,4,heads>", "flops": fl, "exec_flops": 3.0 * (pk.pc1.flops(M) + 2.0 * M * pk.Chid * 32),
+        meta = {"kernel": "conv_x3_kernel<3,1,4,heads>", "flops": fl, "exec_flops": 3.0 * (pk.pc1.flops(M) + 2.0 * M * pk.Chid * 32), "peak_tflops": 2500.0,
                 "bytes": 4.0 * pk.pc1.Cin_real * M + 4.0 * sum(pk.rows) * M + 4.0 * pk.Chid * pk.pc1.Cin_real * 9}
     ptrs = [o.data_ptr() for o in outs] + [None] * (4 - len(outs))
     rows = list(pk.rows) + [0] * (4 - len(outs))

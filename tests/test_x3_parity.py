@@ -154,3 +154,71 @@ def test_elementwise_x3(xo):
     back = torch.zeros(3, 48, 10, 14, device=DEV)
     xo.to_nchw(xv2, ops.View(back, 16, 32))
     assert torch.equal(back[:, 16:48], xv2.nchw()) and float(back[:, :16].abs().max()) == 0
+
+
+# ---- network level: the hybrid engine must pass the fp32 bars unchanged ------------------------------------------------------
+def _x3_model(peaked=False):
+    from util import golden_state_dict
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
+    m.load_state_dict(golden_state_dict(0, peaked=peaked), strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "f32x3"
+    return m
+
+
+@pytest.mark.parametrize("B,H,W,seed", [(2, 128, 160, 11), (1, 480, 640, 321), (3, 96, 224, 13)])
+def test_x3_network_matches_fp32_oracle_at_the_fp32_bar(B, H, W, seed):
+    import oracle
+    from util import ARGS, golden_state_dict
+    from sgtapose_amd.engine_x3 import EngineX3
+    from sgtapose_amd.synthetic import make_inputs
+    m = _x3_model()
+    assert isinstance(m.engine(), EngineX3)
+    inp = make_inputs(B, H, W, seed=seed)
+    out = m(*[inp[k].to(DEV) for k in ARGS])[-1]
+    ref = oracle.plan_a_window_forward(golden_state_dict(0), *[inp[k] for k in ARGS])
+    for k in ("hm", "reg", "tracking"):
+        d = (out[k].cpu() - ref[k]).abs()
+        print("f32x3 vs fp32 oracle %-8s max %.2e mean %.2e" % (k, float(d.max()), float(d.mean())))
+        assert float(d.max()) <= 1e-3, (k, float(d.max()))
+        assert float(d.max()) <= 5e-5, (k, float(d.max()))       # what the emulation actually delivers
+
+
+def test_x3_keypoints_on_peaked_weights_are_the_references():
+    """network -> sigmoid -> decode on the hybrid engine with the peaked weight set: integer peaks and the found / missing table
+    identical to the fp32 oracle's, sub-pixel positions to 1e-3 px -- the fp32 path's own bar."""
+    import numpy as np
+    import oracle
+    from util import ARGS, golden_state_dict
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    m = _x3_model(peaked=True)
+    inp = make_inputs(6, 128, 160, seed=23)
+    out, dets = BatchedDetector(m).process_device(*[inp[k].to(DEV) for k in ARGS])
+    _, rd = oracle.process_reference(golden_state_dict(0, peaked=True), *[inp[k] for k in ARGS])
+    assert int((rd["scores"] >= 0).sum()) >= 3
+    assert np.array_equal(dets["xs"].cpu().numpy(), rd["xs"]) and np.array_equal(dets["ys"].cpu().numpy(), rd["ys"])
+    f = rd["scores"] >= 0
+    assert np.array_equal(dets["scores"].cpu().numpy() >= 0, f)
+    assert float(np.abs(dets["cts_wreg"].cpu().numpy() - rd["cts_wreg"])[f].max()) <= 1e-3
+
+
+def test_x3_step_is_deterministic_across_streams():
+    from util import ARGS
+    from sgtapose_amd.detector import BatchedDetector
+    from sgtapose_amd.synthetic import make_inputs
+    det = BatchedDetector(_x3_model())
+    inp = make_inputs(6, 128, 160, seed=5)
+    dev_in = [inp[k].to(DEV) for k in ARGS]
+    first = None
+    for i in range(8):
+        out, dets = det.process_device(*dev_in, static=True)
+        cur = {k: v.clone() for k, v in out.items()}
+        cur["kp"] = dets["kp"].clone()
+        if first is None:
+            first = cur
+        else:
+            for k in first:
+                assert torch.equal(first[k], cur[k]), (i, k)
+    torch.cuda.synchronize()
