@@ -111,28 +111,31 @@ extern "C" int sgta_window_scatter_x3(const float* tok, int ldt, const long long
   return SGTA_OK;
 }
 
-// fp32 NCHW [N][C][H][W] (x_bs elements per image) <-> x3 blocked.  Thread = (pixel, 8-channel group); a wave covers 64
-// consecutive pixels of one channel group: every fp32 channel plane is read / written in 256-byte runs, the blocked side in
-// 16-byte pieces of consecutive pixels (32-byte stride).
+// fp32 NCHW [N][C][H][W] (x_bs elements per image) <-> x3 blocked.  Thread = (pixel, 16-channel block); a wave covers 64
+// consecutive pixels of one block: every fp32 channel plane is read / written in 256-byte runs and each 16-bit plane in one
+// 2 KB contiguous run (two 16-byte pieces per thread: whole cache lines, no partial-line writes).
 template <bool TO_X3>
 __global__ __launch_bounds__(256) void x3_convert_kernel(float* __restrict__ f, long f_bs, _Float16* __restrict__ h, long h_bs, long h_lo,
-                                                         int C8, long HW, long total) {
+                                                         int Cb, long HW, long total) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long px = i % HW;
     long p = i / HW;
-    const int c = (int)(p % C8) * 8;
-    const long n = p / C8;
-    float* fp = f + n * f_bs + (long)c * HW + px;
-    _Float16* hp = h + n * h_bs + ((long)(c >> 4) * HW + px) * 16 + (c & 15);
-    if (TO_X3) {
-      f32x8 v;
+    const int cb = (int)(p % Cb);
+    const long n = p / Cb;
+    float* fp = f + n * f_bs + (long)cb * 16 * HW + px;
+    _Float16* hp = h + n * h_bs + ((long)cb * HW + px) * 16;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fp[(long)j * HW];
-      x3_store8(hp, h_lo, v);
-    } else {
-      const f32x8 v = x3_load8(hp, h_lo);
+    for (int half = 0; half < 2; ++half) {
+      if (TO_X3) {
+        f32x8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) fp[(long)j * HW] = v[j];
+        for (int j = 0; j < 8; ++j) v[j] = fp[(long)(8 * half + j) * HW];
+        x3_store8(hp + 8 * half, h_lo, v);
+      } else {
+        const f32x8 v = x3_load8(hp + 8 * half, h_lo);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fp[(long)(8 * half + j) * HW] = v[j];
+      }
     }
   }
 }
@@ -140,10 +143,10 @@ __global__ __launch_bounds__(256) void x3_convert_kernel(float* __restrict__ f, 
 extern "C" int sgta_nchw_to_x3(const float* x, long x_bs, void* y, long y_bs, long y_lo_delta, int N, int C, int H, int W,
                                hipStream_t st) {
   if (!x || !y || N <= 0 || C <= 0 || C % 16 || y_bs % 16 || y_lo_delta <= 0 || y_lo_delta % 8 || ((uintptr_t)y & 15)) return SGTA_EBADARG;
-  const long total = (long)N * (C / 8) * H * W;
+  const long total = (long)N * (C / 16) * H * W;
   const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   hipLaunchKernelGGL(x3_convert_kernel<true>, dim3(grid), dim3(256), 0, st, const_cast<float*>(x), x_bs, reinterpret_cast<_Float16*>(y),
-                     y_bs, y_lo_delta, C / 8, (long)H * W, total);
+                     y_bs, y_lo_delta, C / 16, (long)H * W, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }
@@ -151,10 +154,10 @@ extern "C" int sgta_nchw_to_x3(const float* x, long x_bs, void* y, long y_bs, lo
 extern "C" int sgta_x3_to_nchw(const void* x, long x_bs, long x_lo_delta, float* y, long y_bs, int N, int C, int H, int W,
                                hipStream_t st) {
   if (!x || !y || N <= 0 || C <= 0 || C % 16 || x_bs % 16 || x_lo_delta <= 0 || x_lo_delta % 8 || ((uintptr_t)x & 15)) return SGTA_EBADARG;
-  const long total = (long)N * (C / 8) * H * W;
+  const long total = (long)N * (C / 16) * H * W;
   const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
   hipLaunchKernelGGL(x3_convert_kernel<false>, dim3(grid), dim3(256), 0, st, y, y_bs,
-                     reinterpret_cast<_Float16*>(const_cast<void*>(x)), x_bs, x_lo_delta, C / 8, (long)H * W, total);
+                     reinterpret_cast<_Float16*>(const_cast<void*>(x)), x_bs, x_lo_delta, C / 16, (long)H * W, total);
   SGTA_LAUNCH_CHECK();
   return SGTA_OK;
 }

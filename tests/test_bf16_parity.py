@@ -433,7 +433,7 @@ def test_bench_cli_bf16_and_temporal_window_lines():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
             "--height", "128", "--width", "160", "--no-cpu-baseline"]
-    for extra, dtype, unit in ((["--dtype", "bf16"], "bf16", "frame-pairs/s"),
+    for extra, dtype, unit in ((["--dtype", "bf16", "--secondary", "f16,f32x3"], "bf16", "frame-pairs/s"),
                                (["--arch", "dlapawdT_34", "--frames", "4"], "f32", "frame-windows/s")):
         p = subprocess.run(base + extra, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
@@ -442,3 +442,6 @@ def test_bench_cli_bf16_and_temporal_window_lines():
         r = json.loads(lines[0])
         assert r["dtype"] == dtype and r["unit"] == unit and r["value"] > 0
         assert 0 < r["roofline"]["frac"] <= 1.0
+        if dtype == "bf16":                      # further dtypes of the same workload ride in the same JSON line
+            assert sorted(r["secondary"]) == ["f16", "f32x3"]
+            assert all(v["value"] > 0 and 0 < v["roofline"]["frac"] <= 1.0 for v in r["secondary"].values())

@@ -953,7 +953,10 @@ def test_bench_cli_emits_one_json_line_with_roofline_and_parity():
     assert 0 < r["roofline"]["frac"] <= 1.0 and r["roofline"]["bound"] in ("mfma", "hbm")
     par = r["cpu_baseline"]["parity"]
     assert par["hm_max_abs"] < 1e-3 and par["reg_max_abs"] < 1e-3 and par["tracking_max_abs"] < 1e-3
-    assert par["peaked_weights"]["integer_peaks_identical"] and par["peaked_weights"]["keypoint_l2_max_px"] < 1e-3
+    pk = par["peaked_weights"]
+    assert pk["integer_peaks_identical"] and pk["keypoint_l2_max_px_on_shared_peaks"] < 1e-3
+    assert pk["keypoints_same_integer_peak"] == pk["keypoints_found_ref"]
+    assert par["within_bar"] and r["parity_ok"] is True and r["sustained_value"] > 0
     assert r["cpu_baseline"]["cores"] >= 1 and "b8" in r["cpu_baseline"]
 
 
