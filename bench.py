@@ -38,6 +38,7 @@ ARGS = ("x", "pre_img", "pre_hm", "repro_hm", "pre_hm_cls", "repro_hm_cls")
 PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD at 2.4 GHz
 PEAK_TFLOPS_BF16_MFMA = 2500.0      # dense bf16 MFMA (the guide's ~2.5 PF; AMD's 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0               # HBM3E spec
+DTYPE_LABEL = {"f32x3": "f32-emu-f16x3"}      # what the JSON line calls each engine: emulated fp32 never reads as plain f32
 PMC_TABLES = {"f32": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel.csv"),
               "bf16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_bf16.csv"),
               "f16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_f16.csv")}
@@ -550,7 +551,7 @@ def main():
         "ms_per_step": round(1e3 * el / args.steps, 3),
         "host_enqueue_ms_per_step": round(1e3 * enq / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": DTYPE_LABEL.get(args.dtype, args.dtype), "data": "synthetic",
         "config": {"workload": cfg_name + ": batch=%d synthetic %s of %dx%d per GPU, %s random-init (seeded), "
                                "full backbone + temporal attention (6 levels) + DCN neck + heads + sigmoid + peak "
                                "decode%s" % (B, what, H, W, args.arch, " + RCCL all-gather of keypoints" if world > 1 else ""),
@@ -605,7 +606,7 @@ def main():
         for dt in sec:
             w2 = workload(dt)
             el_s, enq_s = timed_steps(w2["run_step"], barrier, args.steps, args.warmup)
-            rec = {"dtype": dt, "value": round(B * args.steps / el_s, 3), "unit": result["unit"], "steps": args.steps,
+            rec = {"dtype": DTYPE_LABEL.get(dt, dt), "value": round(B * args.steps / el_s, 3), "unit": result["unit"], "steps": args.steps,
                    "warmup": args.warmup, "ms_per_step": round(1e3 * el_s / args.steps, 3),
                    "host_enqueue_ms_per_step": round(1e3 * enq_s / args.steps, 3),
                    "workload": "the primary workload (batch=%d, %dx%d, %s) on the %s data path" % (B, H, W, args.arch, dt)}
@@ -701,7 +702,7 @@ def stream_mode(args):
         "metric": "ms/frame, closed-loop video at %dx%d, %d camera(s): raw uint8 frame in -> key-point table out" % (H, W, B),
         "value": best["latency_ms_median"], "unit": "ms", "n_gpus": 1, "steps": steps, "warmup": warm,
         "ms_per_step": best["latency_ms_median"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": DTYPE_LABEL.get(args.dtype, args.dtype), "data": "synthetic",
         "config": {"workload": "stream mode (the reference's SGTADetector.run loop): pre-process -> PnP priors -> two-frame "
                                "network -> decode -> post-process per frame, state on the device; HIP-graph replay",
                    "cameras": B, "net_input": [H, W]},
