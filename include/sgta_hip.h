@@ -470,6 +470,15 @@ int sgta_nchw_to_x3(const float* x, long x_bs, void* y, long y_bs, long y_lo_del
                     sgta_stream_t stream);
 int sgta_x3_to_nchw(const void* x, long x_bs, long x_lo_delta, float* y, long y_bs, int N, int C, int H, int W,
                     sgta_stream_t stream);
+/* The modulated deformable conv of sgta_dcnv2_lds_f32 (reference: lbin/DCNv2 behind DeformConv, dla.py:538-550) on the same fp32
+ * NCHW tensors at fp32 accuracy, with the product on the 16-bit matrix pipe: the bilinear blend runs in fp32, each blended sample
+ * and each weight is an IEEE-half pair (hi + lo), three MFMA products per term.  x 16-byte aligned, x_bs % 4 == 0, W % 4 == 0,
+ * Cin % 8 == 0; om: raw offset / mask conv output [B,27,H,W]; wt: IEEE half [n_ct][Cin/8][5][2][32*mt][16] with n_ct =
+ * ceil(Cout / (32*mt)), k = 8*(tap & 1) + (channel % 8) at step tap / 2, parts hi / lo (wt_bytes = its size, checked); bias f32
+ * [n_ct*32*mt] (BN folded); mt in {2, 4}; log_tw in 3..5: a work-group's tile is (128 >> log_tw) rows x (1 << log_tw) columns;
+ * act 1 = ReLU.  Results do not depend on mt / log_tw beyond fp32 summation order. */
+int sgta_dcnv2_x3(const float* x, long x_bs, const float* om, long om_bs, const void* wt, long wt_bytes, const float* bias,
+                  float* y, long y_bs, int B, int Cin, int H, int W, int Cout, int mt, int log_tw, int act, sgta_stream_t stream);
 
 #ifdef __cplusplus
 }

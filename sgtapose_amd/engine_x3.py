@@ -10,7 +10,8 @@ inside the 1e-3 bar the fp32 fixtures assert.  This engine is a HYBRID of the tw
   level1 -> x3 planes        sgta_nchw_to_x3
   levels 2-5 of the backbone sgta_conv_x3 / sgta_maxpool2_x3 on two-plane blocked maps (the 16-bit conv kernel over 3x the chunks)
   temporal stage             tokens are fp32 as everywhere: sgta_window_gather_x3 / scatter_x3 for levels 2-5, fp32 for 0-1
-  current-frame maps -> fp32 sgta_x3_to_nchw (exact), then the fp32 DCN neck of engine.py (the deformable blend needs fp32 arithmetic)
+  current-frame maps -> fp32 sgta_x3_to_nchw (exact), then engine.py's neck on fp32 NCHW maps: offset convs and up-sampling on the fp32
+                             kernels, the deformable convs through sgta_dcnv2_x3 (fp32 blend, split-operand product)
   neck output -> x3          sgta_nchw_to_x3, then the three head branches in ONE split-operand kernel (sgta_heads_x3), fp32 out
 
 It is reported under its own dtype label, never as plain f32: the arithmetic is emulated, the accuracy is fp32's.
@@ -57,6 +58,12 @@ class EngineX3(Engine):
                                                     getattr(m, h)[2].bias) for h in self.head_names])
         except _lib.SgtaHipError:
             X["heads.fused"] = None    # unusual head configuration: the fp32 head kernels
+        for k, pc in self.P.items():   # the deformable convs of the neck: fp32 tensors in and out, split-operand product
+            if getattr(pc, "tap_major", False):
+                try:
+                    X[k] = xops.PackedDCNX3(pc)
+                except _lib.SgtaHipError:
+                    pass               # Cin % 8 != 0: the fp32 kernel
         self.X = X
 
     def xbuf(self, name, n, h, w, c):
@@ -198,7 +205,15 @@ class EngineX3(Engine):
     def _frame(v, k, B):
         return v.images(k * B, (k + 1) * B) if isinstance(v, ViewX) else View(v.base[k * B:(k + 1) * B])
 
-    # ---- neck on the fp32 kernels, heads on the split-operand kernel ---------------------------------------------------------
+    def _deform(self, name, x, out, om_name="om"):
+        pk = self.X.get(name)
+        if pk is None or not pk.usable(x):
+            return super()._deform(name, x, out, om_name)
+        om = self.vbuf(om_name, x.B, 27, x.H, x.W)
+        ops.conv2d(x, self.P[name + ".om"], om, ACT_NONE)
+        return xops.dcn_v2(x, om, pk, out, ACT_RELU)
+
+    # ---- neck on fp32 NCHW maps (offset convs fp32, deformable convs split-operand), heads on the split-operand kernel ---------------------------------------------------------
     def neck_heads(self, cur, hm_act=ACT_NONE, static=False):
         cur32 = []
         for i, v in enumerate(cur):

@@ -179,6 +179,56 @@ def heads_fused(x, pk, outs, nsig=0):
     return outs
 
 
+class PackedDCNX3:
+    """Weights of sgta_dcnv2_x3, made from the fp32 DCN pack (ops.PackedConv, tap_major): the folded fp32 weights split into
+    IEEE-half hi / lo parts, [n_ct][Cin/8][5 k-steps][hi, lo][BM = 32*mt][16] with k = 8*(tap & 1) + (channel % 8), tap = 2*step +
+    (k >> 3) -- the tenth tap is zero.  One image per work-group width (mt = 2 / 4), built on first use."""
+
+    def __init__(self, pc):
+        w = pc._w_folded
+        if w.shape[2] != 3 or w.shape[1] % 8:
+            raise _lib.SgtaHipError("x3 deformable conv needs a 3x3 kernel and Cin % 8 == 0")
+        self.pc, self.Cin, self.Cout = pc, w.shape[1], w.shape[0]
+        self._packs = {}
+
+    def packed(self, mt):
+        if mt not in self._packs:
+            w, co, ci, bm = self.pc._w_folded, self.Cout, self.Cin, 32 * mt
+            n_ct = -(-co // bm)
+            w10 = torch.zeros(n_ct * bm, ci, 10, device=w.device)
+            w10[:co, :, :9] = w.reshape(co, ci, 9)
+            parts = [p.view(n_ct, bm, ci // 8, 8, 5, 2).permute(0, 2, 4, 1, 5, 3).reshape(n_ct, ci // 8, 5, bm, 16)
+                     for p in split16(w10)]
+            bias = torch.zeros(n_ct * bm, device=w.device)
+            bias[:co] = self.pc.bias[:co]
+            self._packs[mt] = (torch.stack(parts, 3).contiguous(), bias)
+        return self._packs[mt]
+
+    def usable(self, x):
+        return x.W % 4 == 0 and x.bs % 4 == 0 and x.ptr % 16 == 0 and x.W >= 4
+
+
+def dcn_v2(x, om, pk, out, act=ACT_NONE, mt=None):
+    """Fused modulated deformable conv on fp32 NCHW views at fp32 accuracy, the product on the 16-bit matrix pipe.  ``om``: the
+    raw 27-channel offset / mask conv output.  x.W % 4 == 0, 16-byte aligned rows (``pk.usable``)."""
+    from . import ops
+    x, om, out = ops.as_view(x), ops.as_view(om), ops.as_view(out)
+    assert om.C == 27 and x.C == pk.Cin and out.C == pk.Cout and pk.usable(x)
+    code, _ = pk.pc.dcn_tile(x.H, x.W, x.B)
+    if mt is None:
+        mt = code // 10
+    wt, bias = pk.packed(mt)
+    meta = None
+    if _lib.PROFILE is not None:
+        M = x.B * x.H * x.W
+        fl = 2.0 * M * pk.Cout * pk.Cin * 9
+        meta = {"kernel": "dcn_x3_kernel<%d,%d>" % (mt, (32, 16, 8)[code % 10]), "flops": fl, "exec_flops": 3.0 * fl * 10 / 9,
+                "peak_tflops": 2500.0, "bytes": 4.0 * M * (pk.Cin + 27 + pk.Cout) + 4.0 * pk.Cout * pk.Cin * 9}
+    _lib.call("sgta_dcnv2_x3", x.ptr, x.bs, om.ptr, om.bs, wt.data_ptr(), wt.numel() * 2, bias.data_ptr(), out.ptr, out.bs,
+              x.B, pk.Cin, x.H, x.W, pk.Cout, mt, 5 - code % 10, act, _stream(), meta=meta)
+    return out
+
+
 def maxpool2(x, out):
     assert isinstance(x, ViewX) and isinstance(out, ViewX) and out.C == x.C
     _lib.call("sgta_maxpool2_x3", x.ptr, x.bs, x.lo_delta, out.ptr, out.bs, out.lo_delta, x.N, x.C, x.H, x.W, _stream())

@@ -115,6 +115,56 @@ def test_heads_x3_matches_fp32(xo, N, H, W):
         close(o.cpu().double(), r, rel=5e-5)
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,off_scale,mt", [
+    (2, 64, 64, 24, 40, 1.5, 2), (2, 128, 64, 12, 20, 3.0, 2), (1, 512, 256, 6, 12, 1.0, 4), (2, 256, 128, 9, 16, 8.0, 4),
+    (3, 16, 40, 8, 8, 0.0, 2), (2, 64, 128, 30, 44, 0.5, 4), (1, 8, 100, 33, 36, 4.0, 2), (2, 64, 64, 17, 160, 2.0, 2)])
+def test_dcnv2_x3_matches_oracle_and_the_fp32_kernel(xo, B, cin, cout, H, W, off_scale, mt):
+    """sgta_dcnv2_x3 (fp32 blend, split-operand product) against the oracle's DCNv2 restatement at the fp32 kernel's own
+    tolerance, and against the fp32 kernel to 2e-5 of the output's largest magnitude: partial tiles, channel counts that do not
+    fill a work-group, both work-group widths, offsets up to +-8 pixels (in-window and global-fallback samples)."""
+    import oracle
+    from sgtapose_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + H + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    om = torch.randn(B, 27, H, W, generator=g) * off_scale
+    col = oracle.dcn_v2_im2col(x, om[:, :18], torch.sigmoid(om[:, 18:27]))          # [B,Ci,9,H,W]
+    ref = F.relu(torch.matmul(w.reshape(cout, cin * 9).double(), col.reshape(B, cin * 9, H * W).double()).view(B, cout, H, W)
+                 + bias.double().view(1, cout, 1, 1))
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV), tap_major=True)
+    pk = xo.PackedDCNX3(pc)
+    xd, omd = x.to(DEV), om.to(DEV)
+    out = torch.full(ref.shape, float("nan"), device=DEV)
+    assert pk.usable(ops.as_view(xd))
+    xo.dcn_v2(xd, omd, pk, out, ops.ACT_RELU, mt=mt)
+    f32 = torch.full(ref.shape, float("nan"), device=DEV)
+    ops.dcn_v2(xd, omd, pc, f32, ops.ACT_RELU)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err == err and torch.allclose(out.cpu().double(), ref, atol=5e-5, rtol=1e-4), err
+    close(out.double(), f32.double())
+
+
+def test_dcnv2_x3_on_channel_slices_and_batch_views(xo):
+    """Input and output as channel slices of wider buffers, no activation, negative outputs kept."""
+    from sgtapose_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 3, 14, 24
+    big = torch.randn(B, 48, H, W, generator=g)
+    w = torch.randn(24, 32, 3, 3, generator=g) / 17
+    bias = torch.randn(24, generator=g) * 0.1
+    om = torch.randn(B, 27, H, W, generator=g) * 2.0
+    pc = ops.PackedConv(w.to(DEV), bias.to(DEV), tap_major=True)
+    pk = xo.PackedDCNX3(pc)
+    bigd = big.to(DEV)
+    out = torch.zeros(B, 40, H, W, device=DEV)
+    xo.dcn_v2(ops.View(bigd, 8, 32), om.to(DEV), pk, ops.View(out, 8, 24))
+    f32 = torch.zeros(B, 24, H, W, device=DEV)
+    ops.dcn_v2(ops.View(bigd, 8, 32), om.to(DEV), pc, f32)
+    close(out[:, 8:32].double(), f32.double())
+    assert float(f32.min()) < 0 and float(out[:, :8].abs().sum()) == 0 and float(out[:, 32:].abs().sum()) == 0
+
+
 def test_elementwise_x3(xo):
     from sgtapose_amd import ops
     g = torch.Generator().manual_seed(3)
