@@ -177,15 +177,23 @@ __global__ __launch_bounds__(256, 2) void dcn_x3_kernel(DxArgs a) {
             const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
             const int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y0 + 1, 0), H - 1);
             const int qx0 = min(max(x0, 0), W - 2);
+            // all 16 loads in flight at once; opaque: a plain C++ load here gets merged with the LDS reads above into FLAT loads
+            f32x2 g[CK][2];
 #pragma unroll
             for (int j = 0; j < CK; ++j) {
               const float* g0 = xc + (long)j * HW + cy0 * W + qx0;
               const float* g1 = xc + (long)j * HW + cy1 * W + qx0;
-              // opaque loads: a plain C++ load here gets merged with the LDS reads above into FLAT loads
-              f32x2 q0, q1;
-              asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off\n\ts_waitcnt vmcnt(0)"
-                           : "=&v"(q0), "=&v"(q1) : "v"(g0), "v"(g1) : "memory");
-              q[j][0] = q0[0]; q[j][1] = q0[1]; q[j][2] = q1[0]; q[j][3] = q1[1];
+              asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+                           : "=&v"(g[j][0]), "=&v"(g[j][1]) : "v"(g0), "v"(g1) : "memory");
+            }
+            // the wait names every destination register, so no use can be scheduled above it
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(g[0][0]), "+v"(g[0][1]), "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[3][0]), "+v"(g[3][1]),
+                           "+v"(g[4][0]), "+v"(g[4][1]), "+v"(g[5][0]), "+v"(g[5][1]), "+v"(g[6][0]), "+v"(g[6][1]), "+v"(g[7][0]), "+v"(g[7][1])
+                         :: "memory");
+#pragma unroll
+            for (int j = 0; j < CK; ++j) {
+              q[j][0] = g[j][0][0]; q[j][1] = g[j][0][1]; q[j][2] = g[j][1][0]; q[j][3] = g[j][1][1];
             }
           }
         }
@@ -204,7 +212,12 @@ __global__ __launch_bounds__(256, 2) void dcn_x3_kernel(DxArgs a) {
         }
         // toward-zero conversions: the residual v - hi is exact in fp32 and fits 13 bits, of which lo keeps 11
         const auto hp = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-        const auto lp = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)hp[0], v[1] - (float)hp[1]);
+        // residuals v - float(hi) in one instruction each: the half operand is converted inside v_fma_mix_f32
+        float r0, r1;
+        const unsigned hpu = __builtin_bit_cast(unsigned, hp);
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hpu), "v"(v[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hpu), "v"(v[1]));
+        const auto lp = __builtin_amdgcn_cvt_pkrtz(r0, r1);
         hi[j2] = __builtin_bit_cast(unsigned, hp);
         lo[j2] = __builtin_bit_cast(unsigned, lp);
       }

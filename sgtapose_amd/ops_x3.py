@@ -215,8 +215,8 @@ def dcn_v2(x, om, pk, out, act=ACT_NONE, mt=None):
     x, om, out = ops.as_view(x), ops.as_view(om), ops.as_view(out)
     assert om.C == 27 and x.C == pk.Cin and out.C == pk.Cout and pk.usable(x)
     code, _ = pk.pc.dcn_tile(x.H, x.W, x.B)
-    if mt is None:
-        mt = code // 10
+    if mt is None:                                  # 128 output channels per work-group wherever the layer has them: every
+        mt = 4 if pk.Cout % 128 == 0 else 2         # gathered, blended and split sample then feeds 12 MFMAs instead of 6
     wt, bias = pk.packed(mt)
     meta = None
     if _lib.PROFILE is not None:
