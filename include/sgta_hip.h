@@ -470,6 +470,14 @@ int sgta_nchw_to_x3(const float* x, long x_bs, void* y, long y_bs, long y_lo_del
                     sgta_stream_t stream);
 int sgta_x3_to_nchw(const void* x, long x_bs, long x_lo_delta, float* y, long y_bs, int N, int C, int H, int W,
                     sgta_stream_t stream);
+/* The fused input stage of sgta_stem_level0_f16 (both 7x7 stems, their sum, level0: dla.py:259-273, :324-328) at fp32 accuracy on
+ * the 16-bit matrix pipe: the staged input, the stem region and both weight sets are IEEE-half pairs, three MFMA products per
+ * term.  w_stem / w_stem_lo and w_l0 / w_l0_lo: the A fragments of sgta_stem_level0_f16 taken from the hi / lo halves of the folded
+ * fp32 weights.  out_f32 = 0: y = IEEE-half blocked [B][1][H][W][16] (y_bs elements per image), lo plane y_lo_delta elements
+ * behind; out_f32 = 1: y = fp32 NCHW [B,16,H,W] (y_bs elements per image).  W % 4 == 0, 16-byte aligned pointers. */
+int sgta_stem_level0_x3(const float* img, long img_bs, const float* hm, long hm_bs, const void* w_stem, const void* w_stem_lo,
+                        const float* b_stem, const void* w_l0, const void* w_l0_lo, const float* b_l0, void* y, long y_bs,
+                        long y_lo_delta, int out_f32, int B, int H, int W, sgta_stream_t stream);
 /* The modulated deformable conv of sgta_dcnv2_lds_f32 (reference: lbin/DCNv2 behind DeformConv, dla.py:538-550) on the same fp32
  * NCHW tensors at fp32 accuracy, with the product on the 16-bit matrix pipe: the bilinear blend runs in fp32, each blended sample
  * and each weight is an IEEE-half pair (hi + lo), three MFMA products per term.  x 16-byte aligned, x_bs % 4 == 0, W % 4 == 0,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "sgta_window_scatter_x3": [_p, _i, _p, _p, _p, _l, _l, _i, _i, _i, _i, _i, _p],
     "sgta_nchw_to_x3": [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p],
     "sgta_x3_to_nchw": [_p, _l, _l, _p, _l, _i, _i, _i, _i, _p],
+    "sgta_stem_level0_x3": [_p, _l, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _i, _p],
     "sgta_dcnv2_x3": [_p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "sgta_pre_process": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "sgta_pnp_batched": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],

@@ -6,8 +6,8 @@ w = w_hi + w_lo in IEEE half, x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in f
 22 significant bits per operand: results agree with the fp32 operators to ~1e-6 relative (tests/test_x3_parity.py), far
 inside the 1e-3 bar the fp32 fixtures assert.  This engine is a HYBRID of the two existing data paths:
 
-  stems, level0, level1      the fp32 kernels of engine.py (full-resolution, HBM-bound layers: two planes would double their bytes)
-  level1 -> x3 planes        sgta_nchw_to_x3
+  stems + level0             sgta_stem_level0_x3: ONE kernel, the 16-channel stem map never leaves LDS, two-plane output
+  level1                     sgta_conv_x3 (stride 2) on the two-plane level0 map
   levels 2-5 of the backbone sgta_conv_x3 / sgta_maxpool2_x3 on two-plane blocked maps (the 16-bit conv kernel over 3x the chunks)
   temporal stage             tokens are fp32 as everywhere: sgta_window_gather_x3 / scatter_x3 for levels 2-5, fp32 for 0-1
   current-frame maps -> fp32 sgta_x3_to_nchw (exact), then engine.py's neck on fp32 NCHW maps: offset convs and up-sampling on the fp32
@@ -30,6 +30,7 @@ class EngineX3(Engine):
     dtype = "f32x3"
     split_levels = (2, 3, 4, 5)        # levels run as two batch slices on two streams (as engine_bf16.EngineBF16)
     split_parts = 2
+    fuse_stem = True                   # sgta_stem_level0_x3 + level1 as sgta_conv_x3 instead of the fp32 stem / level0 / level1 kernels
 
     def _pack(self, m):
         super()._pack(m)               # fp32 packs: stems, level0 / level1, the DCN neck, token weights (levels 2-5 unused)
@@ -58,6 +59,9 @@ class EngineX3(Engine):
                                                     getattr(m, h)[2].bias) for h in self.head_names])
         except _lib.SgtaHipError:
             X["heads.fused"] = None    # unusual head configuration: the fp32 head kernels
+        X["stem_l0"] = xops.PackedStemL0X3(b.pre_img_layer[0].weight, _bn_tuple(b.pre_img_layer[1]), b.pre_hm_layer[0].weight,
+                                           _bn_tuple(b.pre_hm_layer[1]), b.level0[0].weight, _bn_tuple(b.level0[1]))
+        X["level1"] = PackedConvX3(b.level1[0].weight, None, _bn_tuple(b.level1[1]), stride=2)
         for k, pc in self.P.items():   # the deformable convs of the neck: fp32 tensors in and out, split-operand product
             if getattr(pc, "tap_major", False):
                 try:
@@ -112,18 +116,31 @@ class EngineX3(Engine):
         B, _, H, W = frames[-1][0].shape
         N = len(frames) * B
         P = self.P
-        s = self.buf("stem", (N, 16, H, W))
-        for half, (img, hm) in enumerate(frames):
-            ops.conv_c16(img, hm, P["stem.c16"], View(s[half * B:(half + 1) * B]))
-        lv = [self.vbuf("l0", N, 16, H, W)]
-        ops.conv2d(View(s), P["level0"], lv[0], ACT_RELU)
-        if after_level:
-            after_level(0, lv[0])
-        lv.append(self.vbuf("l1", N, 32, H // 2, W // 2))
-        ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
-        if after_level:
-            after_level(1, lv[1])
-        prev = xops.from_nchw(lv[1], self.xbuf("x.l1", N, H // 2, W // 2, 32))
+        if self.fuse_stem and W % 4 == 0 and all(t.data_ptr() % 16 == 0 for f in frames for t in f):
+            # both stems, their sum and level0 in one split-operand kernel; level1 as a split-operand stride-2 conv
+            lv = [self.xbuf("x.l0", N, H, W, 16)]
+            for half, (img, hm) in enumerate(frames):
+                xops.stem_level0(img.contiguous(), hm.contiguous(), self.X["stem_l0"], lv[0].images(half * B, (half + 1) * B))
+            if after_level:
+                after_level(0, lv[0])
+            lv.append(self.xbuf("x.l1", N, H // 2, W // 2, 32))
+            xops.conv(lv[0], self.X["level1"], lv[1], ACT_RELU)
+            if after_level:
+                after_level(1, lv[1])
+            prev = lv[1]
+        else:
+            s = self.buf("stem", (N, 16, H, W))
+            for half, (img, hm) in enumerate(frames):
+                ops.conv_c16(img, hm, P["stem.c16"], View(s[half * B:(half + 1) * B]))
+            lv = [self.vbuf("l0", N, 16, H, W)]
+            ops.conv2d(View(s), P["level0"], lv[0], ACT_RELU)
+            if after_level:
+                after_level(0, lv[0])
+            lv.append(self.vbuf("l1", N, 32, H // 2, W // 2))
+            ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
+            if after_level:
+                after_level(1, lv[1])
+            prev = xops.from_nchw(lv[1], self.xbuf("x.l1", N, H // 2, W // 2, 32))
         ch = self.model.base.channels
         main = torch.cuda.current_stream()
         parts = self.split_parts if (self.use_side_stream and _lib.PROFILE is None and self.split_levels and N % self.split_parts == 0) else 1
@@ -216,8 +233,9 @@ class EngineX3(Engine):
     # ---- neck on fp32 NCHW maps (offset convs fp32, deformable convs split-operand), heads on the split-operand kernel ---------------------------------------------------------
     def neck_heads(self, cur, hm_act=ACT_NONE, static=False):
         cur32 = []
+        first = self.model.dla_up.startp                                               # the neck reads levels first .. 5 only
         for i, v in enumerate(cur):
-            if isinstance(v, ViewX):
+            if isinstance(v, ViewX) and i >= first:
                 v = xops.to_nchw(v, self.vbuf("l%d.f32" % i, v.N, v.C, v.H, v.W))       # exact
             cur32.append(v)
         feat = self.neck(cur32)

@@ -380,6 +380,7 @@ class PackedStemL0BF16:
             t = 2 * s + (g >> 1)
             for j in range(8):
                 wf[s, :, j] = wl9[cout, 8 * (g & 1) + j, t]
+        self.frag_stem_f32, self.frag_l0_f32 = ws, wf                                      # fp32 fragments (split-operand pack)
         self.w_stem = _to16(ws, dtype).contiguous()
         self.w_l0 = _to16(wf, dtype).contiguous()
         self.b_stem = torch.cat([bi, bh]).float().contiguous()

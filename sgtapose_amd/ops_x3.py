@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from .ops import ACT_NONE, fold_bn, _stream
-from .ops_bf16 import F16, ViewH, PackedConvBF16, _swizzle_rows, HEADS_NPF
+from .ops_bf16 import F16, ViewH, PackedConvBF16, PackedStemL0BF16, _swizzle_rows, HEADS_NPF
 
 OUT_X3_BLOCKED, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
 
@@ -226,6 +226,39 @@ def dcn_v2(x, om, pk, out, act=ACT_NONE, mt=None):
                 "peak_tflops": 2500.0, "bytes": 4.0 * M * (pk.Cin + 27 + pk.Cout) + 4.0 * pk.Cout * pk.Cin * 9}
     _lib.call("sgta_dcnv2_x3", x.ptr, x.bs, om.ptr, om.bs, wt.data_ptr(), wt.numel() * 2, bias.data_ptr(), out.ptr, out.bs,
               x.B, pk.Cin, x.H, x.W, pk.Cout, mt, 5 - code % 10, act, _stream(), meta=meta)
+    return out
+
+
+class PackedStemL0X3(PackedStemL0BF16):
+    """A fragments of sgta_stem_level0_x3: PackedStemL0BF16's fragments of the folded fp32 weights, split into hi / lo halves."""
+
+    def __init__(self, w_img, bn_img, w_hm, bn_hm, w_l0, bn_l0):
+        super().__init__(w_img, bn_img, w_hm, bn_hm, w_l0, bn_l0, dtype=F16)
+        hi, lo = split16(self.frag_stem_f32)
+        self.w_stem, self.w_stem_lo = hi.contiguous(), lo.contiguous()
+        hi, lo = split16(self.frag_l0_f32)
+        self.w_l0, self.w_l0_lo = hi.contiguous(), lo.contiguous()
+
+
+def stem_level0(img, hm, pk, out):
+    """out = level0(relu(bn(conv7x7(img))) + relu(bn(conv7x7(hm)))) in one kernel at fp32 accuracy; img / hm: fp32 NCHW tensors at
+    the API boundary; out: a 16-channel ViewX (two half planes) or an fp32 NCHW ops.View."""
+    assert img.dtype == torch.float32 and hm.dtype == torch.float32 and img.is_contiguous() and hm.is_contiguous()
+    B, _, H, W = img.shape
+    if isinstance(out, ViewX):
+        assert (out.N, out.H, out.W, out.C) == (B, H, W, 16) and out.base.shape[1] == 1
+        yptr, ybs, ylo, f32 = out.ptr, out.bs, out.lo_delta, 0
+    else:
+        assert (out.B, out.C, out.H, out.W) == (B, 16, H, W)
+        yptr, ybs, ylo, f32 = out.ptr, out.bs, 0, 1
+    meta = None
+    if _lib.PROFILE is not None:
+        M = B * H * W
+        meta = {"kernel": "stem_l0_x3_kernel", "flops": pk.flops(M), "exec_flops": 3.0 * 2.0 * M * 16 * (14 * 32 + 5 * 32),
+                "peak_tflops": 2500.0, "bytes": M * (16.0 + 64.0)}
+    _lib.call("sgta_stem_level0_x3", img.data_ptr(), 3 * H * W, hm.data_ptr(), H * W, pk.w_stem.data_ptr(), pk.w_stem_lo.data_ptr(),
+              pk.b_stem.data_ptr(), pk.w_l0.data_ptr(), pk.w_l0_lo.data_ptr(), pk.b_l0.data_ptr(), yptr, ybs, ylo, f32, B, H, W,
+              _stream(), meta=meta)
     return out
 
 

@@ -165,6 +165,33 @@ def test_dcnv2_x3_on_channel_slices_and_batch_views(xo):
     assert float(f32.min()) < 0 and float(out[:, :8].abs().sum()) == 0 and float(out[:, 32:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 32, 128), (1, 19, 68), (3, 8, 64), (1, 41, 200)])
+def test_stem_level0_x3_matches_fp64(xo, B, H, W):
+    """sgta_stem_level0_x3 (both 7x7 stems with their own ReLUs, their sum, level0: one kernel) against torch in fp64 on the
+    unrounded operands: both output forms (two half planes / fp32 NCHW), partial tiles in both directions, folded BatchNorm."""
+    from sgtapose_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    rnd = lambda *s: torch.randn(*s, generator=g)                                  # noqa: E731
+    bn = lambda c: (rnd(c).abs() + 0.5, rnd(c) * 0.2, rnd(c) * 0.1, rnd(c).abs() + 0.5)   # noqa: E731
+    w_img, w_hm, w_l0 = rnd(16, 3, 7, 7) / 12, rnd(16, 1, 7, 7) / 7, rnd(16, 16, 3, 3) / 12
+    bns = [bn(16) for _ in range(3)]
+    img, hm = rnd(B, 3, H, W) * 1.5, rnd(B, 1, H, W).abs().clamp(max=1.0)
+    fold = lambda w, p: ops.fold_bn(w.double(), None, tuple(t.double() for t in p))    # noqa: E731
+    (wi, bi), (wh, bh), (wl, bl) = fold(w_img, bns[0]), fold(w_hm, bns[1]), fold(w_l0, bns[2])
+    stem = F.relu(F.conv2d(img.double(), wi, bi, padding=3)) + F.relu(F.conv2d(hm.double(), wh, bh, padding=3))
+    ref = F.relu(F.conv2d(stem, wl, bl, padding=1))
+    d = lambda t: tuple(u.to(DEV) for u in t)                                       # noqa: E731
+    pk = xo.PackedStemL0X3(w_img.to(DEV), d(bns[0]), w_hm.to(DEV), d(bns[1]), w_l0.to(DEV), d(bns[2]))
+    out = xo.ViewX.alloc(B, 16, H, W, DEV)
+    out.base.fill_(7.0)
+    xo.stem_level0(img.to(DEV), hm.to(DEV), pk, out)
+    close(out.nchw().cpu().double(), ref)
+    o32 = torch.full((B, 16, H, W), float("nan"), device=DEV)
+    xo.stem_level0(img.to(DEV), hm.to(DEV), pk, ops.View(o32))
+    close(o32.cpu().double(), ref)
+    assert float((o32 - out.nchw()).abs().max()) <= 4e-7 * float(ref.abs().max())     # the planes hold the fp32 result to 22 bits
+
+
 def test_elementwise_x3(xo):
     from sgtapose_amd import ops
     g = torch.Generator().manual_seed(3)
