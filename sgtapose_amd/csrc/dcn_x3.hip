@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256, 2) void dcn_x3_kernel(DxArgs a) {
       float q[CK][4];
 #pragma unroll
       for (int j = 0; j < CK; ++j) {
+#if defined(DX_ABLATE) && (DX_ABLATE & 1)
+        q[j][0] = pw[s][0] + j; q[j][1] = pw[s][1]; q[j][2] = pw[s][2]; q[j][3] = pw[s][3];      // tools only: no gather reads
+#else
         q[j][0] = p0[j * PSZ]; q[j][1] = p0[j * PSZ + 1]; q[j][2] = p1[j * PSZ]; q[j][3] = p1[j * PSZ + 1];
+#endif
       }
       if (SLOW) {
         // wave-uniform test first: steps in which no lane of the wave samples outside the window cost nothing
@@ -199,6 +203,13 @@ __global__ __launch_bounds__(256, 2) void dcn_x3_kernel(DxArgs a) {
         }
       }
       dx_u4 hi, lo;
+#if defined(DX_ABLATE) && (DX_ABLATE & 8)
+#pragma unroll
+      for (int j2 = 0; j2 < CK / 2; ++j2) {      // tools only: no blend, no split
+        hi[j2] = __builtin_bit_cast(unsigned, q[2 * j2][0]);
+        lo[j2] = __builtin_bit_cast(unsigned, q[2 * j2 + 1][2]);
+      }
+#else
 #pragma unroll
       for (int j2 = 0; j2 < CK / 2; ++j2) {
         float v[2];
@@ -221,19 +232,30 @@ __global__ __launch_bounds__(256, 2) void dcn_x3_kernel(DxArgs a) {
         hi[j2] = __builtin_bit_cast(unsigned, hp);
         lo[j2] = __builtin_bit_cast(unsigned, lp);
       }
+#endif
       const dx_h8 bh = __builtin_bit_cast(dx_h8, hi), bl = __builtin_bit_cast(dx_h8, lo);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
+#if defined(DX_ABLATE) && (DX_ABLATE & 16)
+        const dx_h8 ah = __builtin_bit_cast(dx_h8, hi), al = __builtin_bit_cast(dx_h8, lo);         // tools only: no weight reads
+#else
         const dx_h8 ah = *reinterpret_cast<const dx_h8*>(As + ((s * 2 + 0) * BM + i * 32 + l31) * 16 + lh * 8);
         const dx_h8 al = *reinterpret_cast<const dx_h8*>(As + ((s * 2 + 1) * BM + i * 32 + l31) * 16 + lh * 8);
+#endif
+#if defined(DX_ABLATE) && (DX_ABLATE & 2)
+        acc[i][0] += (float)ah[0] * (float)bh[0] + (float)al[1] * (float)bl[1];                     // tools only: no MFMA
+#else
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i], 0, 0, 0);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i], 0, 0, 0);
+#endif
       }
     }
     if (kc + 1 < a.nchunks) {
       __syncthreads();                             // every wave has read this chunk: the single stage may be overwritten
+#if !(defined(DX_ABLATE) && (DX_ABLATE & 4))
       stage(kc + 1);
+#endif
     }
   };
   if (any_out) {

@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
     args = ap.parse_args()
-    from sgtapose_amd import ops, ops_x3 as xops
+    from sgtapose_amd import _lib, ops, ops_x3 as xops
+    if os.environ.get("SGTA_LIB"):                 # ablation builds (tools/dcn_x3_ablate.sh)
+        _lib.LIB_PATH = os.environ["SGTA_LIB"]
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(1)
     B = args.batch
