@@ -268,22 +268,32 @@ __global__ __launch_bounds__(256, 2) void stem_l0_x3_kernel(SxArgs a) {
   };
 
   // ---- phase 1: fp32 window -> two half planes [row][col][4 channels] in LDS (zero outside the image) ------------------------
-  for (int e = tid; e < WH * WQ; e += 256) {
+  // (all loads of a thread's items are issued before the first conversion: one memory latency per work-group, not one per item)
+  constexpr int NIT = (WH * WQ + 255) / 256;
+  f32x4 v[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 256;
     const int r = e / WQ, q = e - r * WQ;
     const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
-    f32x4 v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+    for (int c = 0; c < 4; ++c) v[it][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (e < WH * WQ && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
       const float* src = a.img + (long)b * a.img_bs + (long)gy * W + gx;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = *reinterpret_cast<const f32x4*>(src + c * HW);
-      v[3] = *reinterpret_cast<const f32x4*>(a.hm + (long)b * a.hm_bs + (long)gy * W + gx);
+      for (int c = 0; c < 3; ++c) v[it][c] = *reinterpret_cast<const f32x4*>(src + c * HW);
+      v[it][3] = *reinterpret_cast<const f32x4*>(a.hm + (long)b * a.hm_bs + (long)gy * W + gx);
     }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 256;
+    if (e >= WH * WQ) break;
+    const int r = e / WQ, q = e - r * WQ;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       h4 hi, lo;
-      split4(f32x4{v[0][i], v[1][i], v[2][i], v[3][i]}, hi, lo);
+      split4(f32x4{v[it][0][i], v[it][1][i], v[it][2][i], v[it][3][i]}, hi, lo);
       *reinterpret_cast<h4*>(win + (r * WS + 4 * q + i) * 8) = hi;
       *reinterpret_cast<h4*>(win + WIN_BYTES + (r * WS + 4 * q + i) * 8) = lo;
     }

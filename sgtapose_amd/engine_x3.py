@@ -231,22 +231,61 @@ class EngineX3(Engine):
         return xops.dcn_v2(x, om, pk, out, ACT_RELU)
 
     # ---- neck on fp32 NCHW maps (offset convs fp32, deformable convs split-operand), heads on the split-operand kernel ---------------------------------------------------------
+    neck_parts = 1                     # > 1: neck + heads as that many batch slices on as many streams
+
     def neck_heads(self, cur, hm_act=ACT_NONE, static=False):
-        cur32 = []
         first = self.model.dla_up.startp                                               # the neck reads levels first .. 5 only
-        for i, v in enumerate(cur):
-            if isinstance(v, ViewX) and i >= first:
-                v = xops.to_nchw(v, self.vbuf("l%d.f32" % i, v.N, v.C, v.H, v.W))       # exact
-            cur32.append(v)
-        feat = self.neck(cur32)
-        self.last_feat = feat
         pk = self.X.get("heads.fused")
-        if pk is None:
-            return self.heads(feat, hm_act, static)
-        B, h, w = feat.B, feat.H, feat.W
-        fx = xops.from_nchw(feat, self.xbuf("x.feat", B, h, w, feat.C))
+
+        def neck_slice(lo, hi):
+            cur32 = []
+            for i, v in enumerate(cur):
+                if i >= first:
+                    v = self._images(v, lo, hi)
+                    if isinstance(v, ViewX):
+                        v = xops.to_nchw(v, self.vbuf("l%d.f32" % i, v.N, v.C, v.H, v.W))   # exact
+                cur32.append(v)
+            return self.neck(cur32)
+
+        B = cur[-1].N if isinstance(cur[-1], ViewX) else cur[-1].B
+        parts = self.neck_parts if (self.use_side_stream and _lib.PROFILE is None and pk is not None) else 1
+        if parts <= 1 or B % parts:
+            feat = neck_slice(0, B)
+            self.last_feat = feat
+            if pk is None:
+                return self.heads(feat, hm_act, static)
+        h, w = cur[first].H, cur[first].W
         outs = [self.buf("out_" + n, (B, r, h, w)) if static else torch.empty((B, r, h, w), dtype=torch.float32, device=self.dev)
                 for n, r in zip(self.head_names, pk.rows)]
         nsig = pk.rows[0] if (self.head_names[0] == "hm" and hm_act == ops.ACT_SIGMOID) else 0
-        xops.heads_fused(fx, pk, outs, nsig)
+
+        def heads_slice(feat, lo, hi):
+            fx = xops.from_nchw(feat, self.xbuf("x.feat", feat.B, h, w, feat.C))
+            xops.heads_fused(fx, pk, [o[lo:hi] for o in outs], nsig)
+
+        if parts <= 1 or B % parts:
+            heads_slice(feat, 0, B)
+            return dict(zip(self.head_names, outs))
+        main, hb = torch.cuda.current_stream(), B // parts
+        streams = self._part_streams(parts - 1)
+        saved, self.use_side_stream = self.use_side_stream, False       # a slice's neck runs serially on its own stream
+        try:
+            for k, st in enumerate(streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self.buf_tag = ".n%d" % (k + 1)
+                    try:
+                        heads_slice(neck_slice((k + 1) * hb, (k + 2) * hb), (k + 1) * hb, (k + 2) * hb)
+                    finally:
+                        self.buf_tag = ""
+            self.last_feat = neck_slice(0, hb)
+            heads_slice(self.last_feat, 0, hb)
+        finally:
+            self.use_side_stream = saved
+        for st in streams:
+            main.wait_stream(st)
         return dict(zip(self.head_names, outs))
+
+    @staticmethod
+    def _images(v, lo, hi):
+        return v.images(lo, hi) if isinstance(v, ViewX) else View(v.base[lo:hi], v.c0, v.C)
