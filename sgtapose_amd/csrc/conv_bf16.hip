@@ -78,7 +78,8 @@ __device__ __forceinline__ void cb_wait_vm() {
 // significant bits on IEEE half), product = x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 (the dropped x_lo w_lo term
 // is 2^-22 relative).  For the kernel this is a convolution over 3x the chunks: virtual chunk v = 3 kc + p reads the window
 // of real chunk kc from the hi plane (p = 0, 1) or the lo plane (p = 2), and the packed weights hold [w_hi, w_lo, w_hi] per real
-// chunk (ops_x3.py); the epilogue splits the fp32 result into the two output planes.
+// chunk (ops_x3.py); the epilogue splits the fp32 result into the two output planes.  Pass p = 1 reads the window that pass
+// p = 0 staged (no second fetch of the hi plane: the window fill, not the matrix pipe, bounds these kernels).
 template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   static_assert(!P3 || (KS == 3 && KC == 16), "the three-deep pipeline is built for 3x3 convolutions");
@@ -154,21 +155,23 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
     return rk * (KC / 16) * a.H * a.W * 32 + (pp3 == 2 ? a.x_lo_delta : 0);
   };
   // DMA instruction j (0 .. NDMA-1) of chunk kc (weight image wi) into stage st: window rounds first, then the weight image
+  // (the window part of stage buffer ``wsl`` and the weight part of stage buffer ``st``: the two advance separately under X3,
+  // whose middle pass reads the window of the pass before it)
   constexpr int NDMA = G::WROUNDS + AROUNDS;
-  auto dma_one = [&](int j, int kc, int wi, int st) {
+  auto dma_one = [&](int j, int kc, int wi, int st, int wsl) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned char* wdst = smem + st * STAGE + wave * 1024;
     if (j < G::WROUNDS)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(wdst + j * 8192), 16, woff[j < G::WROUNDS ? j : 0],
-                                               src_off(kc), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem + wsl * STAGE + wave * 1024 + j * 8192), 16,
+                                               woff[j < G::WROUNDS ? j : 0], src_off(kc), 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wdst + G::WIN_BYTES + (j - G::WROUNDS) * 8192), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(smem + st * STAGE + wave * 1024 + G::WIN_BYTES + (j - G::WROUNDS) * 8192), 16,
                                                aoffw[j >= G::WROUNDS ? j - G::WROUNDS : 0], wi * WIMG, 0, 0);
 #endif
   };
-  auto stage = [&](int kc, int wi, int st) {
+  auto stage = [&](int kc, int wi, int st, int wsl, bool with_win) {
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) dma_one(j, kc, wi, st);
+    for (int j = 0; j < NDMA; ++j)
+      if (j >= G::WROUNDS || with_win) dma_one(j, kc, wi, st, wsl);
   };
 
   // ---- per-lane output positions and LDS fragment addresses -----------------------------------------------------
@@ -281,20 +284,23 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
     dma_win(0, 0);
     dma_wts(3 * wi0, 0);
     dma_wts(3 * wi0 + 1, 1);
+    int wslot = 0, ph = 0;                                 // window slot of this chunk; X3: pass of this chunk (kc % 3)
     for (int it = 0; it < n_it; ++it) {
-      const bool more_chunk = it + 1 < n_it;
       const int nkc = kc + 1 < a.nchunks ? kc + 1 : 0;
-      const unsigned char* Ws = win0 + (it & 1) * G::WIN_BYTES;
+      const int nph = ph == 2 ? 0 : ph + 1;
+      const bool next_new = !X3 || nph != 1;               // the next chunk reads a window of its own
+      const bool fetch = it + 1 < n_it && next_new;
+      const unsigned char* Ws = win0 + wslot * G::WIN_BYTES;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int s_ = 3 * it + j;
         // everything issued BEFORE the data of this sub-step has landed once only the later loads are outstanding:
         // the weight image of sub-step s + 1 (issued one sub-step ago) and, behind j == 0, the next chunk's window
         if (s_ + 1 >= total) cb_wait_vm<0>();
-        else if (j == 1 && more_chunk) cb_wait_vm<AW + WRN>();
+        else if (j == 1 && fetch) cb_wait_vm<AW + WRN>();
         else cb_wait_vm<AW>();
         __builtin_amdgcn_s_barrier();
-        if (j == 0 && more_chunk) dma_win(nkc, (it + 1) & 1);
+        if (j == 0 && fetch) dma_win(nkc, wslot ^ 1);
         if (s_ + 2 < total) dma_wts(3 * wi0 + s_ + 2, (j + 2) % 3);
         const unsigned char* As = wts0 + j * WSUB;
         bf16x8 afr[2][NA], bfr[2][NPF];
@@ -317,24 +323,30 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       }
       if (FUSE && nkc == 0) heads_tile();
       kc = nkc;
+      ph = nph;
+      if (next_new) wslot ^= 1;
     }
   } else {
   // a.single: ONE LDS stage (a chunk's DMA is issued when every wave is done with the previous one and waited for at once),
   // half the LDS -> twice the work-groups per CU: for layers of a few chunks the other work-group's matrix work covers the
   // wait better than a second stage of the same work-group does
-  stage(0, wi0, 0);
+  stage(0, wi0, 0, 0, true);
+  int wslot = 0, ph = 0;                           // stage buffer that holds this chunk's window; X3: pass of this chunk (kc % 3)
   for (int it = 0; it < n_it; ++it) {
     const int st = a.single ? 0 : (it & 1);
     if (a.single && it) {
       __builtin_amdgcn_s_barrier();                // every wave has read chunk it - 1
-      stage(kc, wi0 + it, 0);
+      stage(kc, wi0 + it, 0, 0, !X3 || ph != 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = !a.single && it + 1 < n_it;  // the next chunk's DMA is issued piece by piece between the MFMA groups below
     const int nkc = kc + 1 < a.nchunks ? kc + 1 : 0;
-    const unsigned char* Ws = smem + st * STAGE;
-    const unsigned char* As = Ws + G::WIN_BYTES;
+    const int nph = ph == 2 ? 0 : ph + 1;
+    const bool next_new = !X3 || nph != 1;         // the next chunk reads a window of its own (X3: not the middle pass)
+    const int nwslot = a.single ? 0 : (next_new ? wslot ^ 1 : wslot);
+    const unsigned char* Ws = smem + wslot * STAGE;
+    const unsigned char* As = smem + st * STAGE + G::WIN_BYTES;
     // software pipeline over the k-steps of the chunk: the fragments of step k + 1 are requested before the MFMAs of step
     // k issue, so the LDS latency sits under matrix work of the SAME wave (the two waves of a SIMD run this loop in
     // lock-step after the barrier and would otherwise wait on LDS together, then contend for the matrix pipe together)
@@ -362,11 +374,13 @@ __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
       if (more) {
 #pragma unroll
         for (int d = 0; d < DPK; ++d)
-          if (k * DPK + d < NDMA) dma_one(k * DPK + d, nkc, wi0 + it + 1, st ^ 1);
+          if (k * DPK + d < NDMA && (k * DPK + d >= G::WROUNDS || next_new)) dma_one(k * DPK + d, nkc, wi0 + it + 1, st ^ 1, nwslot);
       }
     }
     if (FUSE && nkc == 0) heads_tile();
     kc = nkc;
+    ph = nph;
+    wslot = nwslot;
   }
   }
 

@@ -47,7 +47,9 @@ def main():
     ap.add_argument("--x3", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
     args = ap.parse_args()
-    from sgtapose_amd import ops_bf16 as bops
+    from sgtapose_amd import _lib, ops_bf16 as bops
+    if os.environ.get("SGTA_LIB"):                 # ablation builds (-DCB_ABLATE=k: 1 no window fetch, 2 no weight fetch)
+        _lib.LIB_PATH = os.environ["SGTA_LIB"]
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(1)
