@@ -41,7 +41,8 @@ PEAK_HBM_GBS = 8000.0               # HBM3E spec
 DTYPE_LABEL = {"f32x3": "f32-emu-f16x3"}      # what the JSON line calls each engine: emulated fp32 never reads as plain f32
 PMC_TABLES = {"f32": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel.csv"),
               "bf16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_bf16.csv"),
-              "f16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_f16.csv")}
+              "f16": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_f16.csv"),
+              "f32x3": os.path.join(REPO, "profiles", "r03_pmc_step_by_kernel_f32x3.csv")}
 
 
 def log(*a):

@@ -26,8 +26,12 @@ def family(name):
     args = [a.strip() for a in name.split("<")[1].split(">")[0].split(",")] if "<" in name else []
     if "wino" in fam and args:                        # keep the tile shape: same spelling as bench.py's table
         fam += "<%s>" % args[0]
-    elif fam == "conv_bf16_kernel" and len(args) >= 5:    # <KS, S, KC, NPF, NA, FUSE, P3> -> bench.py's <KS,S,NA[,heads]>
+    elif fam == "conv_bf16_kernel" and len(args) >= 5:    # <KS, S, KC, NPF, NA, FUSE, P3, F16, X3> -> bench.py's <KS,S,NA[,heads]>
+        if len(args) > 8 and args[8] in ("true", "1"):     # split-operand instantiation: bench.py's conv_x3_kernel
+            fam = "conv_x3_kernel"
         fam += "<%s,%s,%s%s>" % (args[0], args[1], args[4], ",heads" if len(args) > 5 and args[5] == "1" else "")
+    elif fam == "dcn_x3_kernel" and len(args) >= 2:       # <MT, TW, ACT> -> <MT,TW>
+        fam += "<%s,%s>" % (args[0], args[1])
     elif fam == "dcn_bf16_kernel" and args:               # <NA, R, PR> -> <NA>
         fam += "<%s>" % args[0]
     return fam
