@@ -659,7 +659,7 @@ def stream_mode(args):
                     [0.25, 0.15, 0.35]], np.float64)
     x3d = np.stack([pts] * B)
     camK = np.array([[0.94 * W, 0, W / 2.0], [0, 0.94 * W, H / 2.0], [0, 0, 1.0]])
-    dtypes = [args.dtype] + [d for d in (args.secondary if args.secondary is not None else "bf16,f16").split(",")
+    dtypes = [args.dtype] + [d for d in (args.secondary if args.secondary is not None else "f32x3,bf16,f16").split(",")
                              if d and d != args.dtype]
     rec = {}
     for dt in dtypes:

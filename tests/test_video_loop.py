@@ -107,14 +107,15 @@ def _run(runner, frames, x3ds, seeds):
     return rec
 
 
-def test_closed_loop_video_matches_the_oracle_chain():
+@pytest.mark.parametrize("dtype", ["f32", "f32x3"])
+def test_closed_loop_video_matches_the_oracle_chain(dtype):
     from sgtapose_amd.stream import VideoRunner
     T = 8
     frames = _frames(T)
     x3ds, proj = _robot(T)
     seeds = {4: proj[3].copy()}                    # frame 4 starts from known detections of frame 3: the PnP branch is certain
     seeds[4][5] = MISSING                          # ... with one key-point missing
-    m, sd = _model(peaked=True)
+    m, sd = _model(peaked=True, dtype=dtype)
     ref = _oracle_loop(sd, frames, x3ds, float(m.opt.out_thresh), seeds, proj)
     print("seeded frames:", sorted(seeds))
     got = _run(VideoRunner(m, (HR, WR), CAM_K, batch=1), frames, x3ds, seeds)
@@ -132,7 +133,7 @@ def test_closed_loop_video_matches_the_oracle_chain():
     assert ref[0]["priors"] == 0 and n_prior >= 2 and n_det >= 3
 
 
-@pytest.mark.parametrize("dtype,B", [("f32", 1), ("f32", 2), ("f16", 1)])
+@pytest.mark.parametrize("dtype,B", [("f32", 1), ("f32", 2), ("f16", 1), ("f32x3", 1)])
 def test_graph_captured_loop_reproduces_the_eager_loop_on_every_replay(dtype, B):
     """The steady-state step captured in a HIP graph (one per buffer parity) against the eager loop, frame by frame, with
     the program's own eager work (seeding, host copies, synchronisation) between the replays: bit-identical."""
