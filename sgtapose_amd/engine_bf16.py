@@ -34,6 +34,12 @@ class EngineBF16(Engine):
         with bops.pack_dtype(self.act_dtype):
             super().__init__(model)
     fuse_heads = True         # sgta_heads_bf16: the 3x3 -> ReLU -> 1x1 branches in one kernel, no hidden tensor in memory
+    kops = bops               # kernel faces of this data path (the multi-frame engines are written against these three hooks)
+    conv_packs = property(lambda self: self.P)
+
+    def mbuf(self, name, n, h, w, c):
+        return self.hbuf(name, n, h, w, c)
+
     fuse_stem = True          # sgta_stem_level0_bf16 (bf16 MFMA, stem map in LDS) instead of the f32 stem kernel + level0 conv
 
     # ------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ structure on engine_bf16.EngineBF16's kernels.
 """
 import torch
 
-from . import _lib, ops, ops_bf16 as bops
+from . import _lib, ops
 from .engine_bf16 import EngineBF16
 from .engine_three import EngineThree
 from .ops import ACT_NONE, ACT_RELU
@@ -22,12 +22,17 @@ class EngineSeqBF16(EngineBF16):
 
     def _pack(self, m):
         super()._pack(m)
+        self._pack_seq(m, PackedConvBF16, self.P)
+
+    def _pack_seq(self, m, pack_conv, dest):
+        """Token-encoder weights per previous frame; the full-map cat-MLP of levels 3-5 as 1x1 convolutions (``pack_conv``
+        objects stored in ``dest``), one weight block per frame."""
         self.T = int(m.n_frames)
         self.legacy_slip = bool(m.legacy_slip)
         n_prev = self.T - 1
         self.tf_k = [[self._pack_encoder(m.frame_transformer[k][i]) for i in range(3)] for k in range(n_prev)]
         self.tf = self.tf_k[-1]
-        for i in (3, 4, 5):                              # full-map cat-MLP as 1x1 convs, one weight block per frame
+        for i in (3, 4, 5):
             s = m.cat_layer[i]
             C = s[2].out_features
             w0 = s[0].weight.detach().float()
@@ -36,13 +41,14 @@ class EngineSeqBF16(EngineBF16):
                 blk = [None, blk[0] + blk[1], blk[2]]
             for k in range(n_prev):
                 if blk[k] is not None:
-                    self.P["cat%d.f%d" % (i, k)] = PackedConvBF16(blk[k].reshape(-1, C, 1, 1).contiguous(), None)
-            self.P["cat%d.cur" % i] = PackedConvBF16(blk[-1].reshape(-1, C, 1, 1).contiguous(), s[0].bias)
-            self.P["cat%d.out" % i] = PackedConvBF16(s[2].weight.detach().float().reshape(C, -1, 1, 1).contiguous(), s[2].bias)
+                    dest["cat%d.f%d" % (i, k)] = pack_conv(blk[k].reshape(-1, C, 1, 1).contiguous(), None)
+            dest["cat%d.cur" % i] = pack_conv(blk[-1].reshape(-1, C, 1, 1).contiguous(), s[0].bias)
+            dest["cat%d.out" % i] = pack_conv(s[2].weight.detach().float().reshape(C, -1, 1, 1).contiguous(), s[2].bias)
 
     # ------------------------------------------------------------------------------------------
     def temporal_seq(self, lv, idxs, B, levels=range(6)):
         K, T = self.num_classes, self.T
+        CP = self.conv_packs
         n_prev = T - 1
         for i in levels:
             feats = lv[i]
@@ -60,25 +66,25 @@ class EngineSeqBF16(EngineBF16):
                                                 self.buf("fid%d_%d" % (k, i), (2, B, n), torch.int64),
                                                 self.buf("win%d_%d" % (k, i), (B, n), torch.uint8))
                     if k == 0:
-                        bops.window_gather(cur_f, fid[1], qry)
-                        bops.window_gather(cur_f, fid[1], cat_tok, col0=n_prev * C)
+                        self.kops.window_gather(cur_f, fid[1], qry)
+                        self.kops.window_gather(cur_f, fid[1], cat_tok, col0=n_prev * C)
                     key = self.buf("key%d_%d" % (k, i), (M, C))
-                    bops.window_gather(frame[k], fid[0], key)
+                    self.kops.window_gather(frame[k], fid[0], key)
                     self._encoder(self.tf_k[k][i], "f%d_" % k, i, key, qry, cat_tok[:, k * C:(k + 1) * C], B, n)
                 Cc = self.cat[i]
                 h1 = ops.linear(cat_tok, Cc["w0"], Cc["b0"], self.buf("cat_h%d" % i, (M, 2 * T * C)), relu=True)
                 z = ops.linear(h1, Cc["w2"], Cc["b2"], self.buf("cat_z%d" % i, (M, C)))
-                bops.window_scatter(z, fid[1], win, cur_f)
+                self.kops.window_scatter(z, fid[1], win, cur_f)
             else:
-                ta = self.hbuf("cat_ta%d" % i, B, H, W, 2 * T * C)
-                tb = self.hbuf("cat_tb%d" % i, B, H, W, 2 * T * C)
-                bops.conv(cur_f, self.P["cat%d.cur" % i], ta, ACT_NONE)
-                ks_ = [k for k in range(n_prev) if ("cat%d.f%d" % (i, k)) in self.P]
+                ta = self.mbuf("cat_ta%d" % i, B, H, W, 2 * T * C)
+                tb = self.mbuf("cat_tb%d" % i, B, H, W, 2 * T * C)
+                self.kops.conv(cur_f, CP["cat%d.cur" % i], ta, ACT_NONE)
+                ks_ = [k for k in range(n_prev) if ("cat%d.f%d" % (i, k)) in CP]
                 for j, k in enumerate(ks_):
                     last = j == len(ks_) - 1
-                    bops.conv(frame[k], self.P["cat%d.f%d" % (i, k)], tb, ACT_RELU if last else ACT_NONE, res=ta)
+                    self.kops.conv(frame[k], CP["cat%d.f%d" % (i, k)], tb, ACT_RELU if last else ACT_NONE, res=ta)
                     ta, tb = tb, ta
-                bops.conv(ta, self.P["cat%d.out" % i], cur_f, ACT_NONE)
+                self.kops.conv(ta, CP["cat%d.out" % i], cur_f, ACT_NONE)
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x, pre_imgs, pre_hms, repro_hm, pre_hm_clss, repro_hm_cls, hm_act=ACT_NONE, static=False):

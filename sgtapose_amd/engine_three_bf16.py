@@ -3,7 +3,7 @@ structure (two encoder passes per level 0-2, the folded ``cat[pre, pre, cur]`` 1
 engine_bf16.EngineBF16's kernels.  Token kernels stay fp32; the level 3-5 cat-MLP runs as bf16 1x1 convolutions."""
 import torch
 
-from . import _lib, ops, ops_bf16 as bops
+from . import _lib, ops
 from .engine_bf16 import EngineBF16
 from .engine_three import EngineThree
 from .ops import ACT_NONE, ACT_RELU
@@ -15,18 +15,22 @@ class EngineThreeBF16(EngineBF16):
 
     def _pack(self, m):
         super()._pack(m)
+        self._pack_three(m, PackedConvBF16, self.P)
+
+    def _pack_three(self, m, pack_conv, dest):
         self.tf = [self._pack_encoder(m.prev_transformer[i]) for i in range(3)]
         self.tf_pp = self.tf if m.shared_ca else [self._pack_encoder(m.pprev_transformer[i]) for i in range(3)]
         for i in (3, 4, 5):                              # full-map cat-MLP as 1x1 convs (the two ``pre`` slices folded)
             s = m.cat_layer[i]
             C = s[2].out_features
             w0 = s[0].weight.detach().float()
-            self.P["cat%d.pre" % i] = PackedConvBF16((w0[:, :C] + w0[:, C:2 * C]).reshape(-1, C, 1, 1).contiguous(), None)
-            self.P["cat%d.cur" % i] = PackedConvBF16(w0[:, 2 * C:].reshape(-1, C, 1, 1).contiguous(), s[0].bias)
-            self.P["cat%d.out" % i] = PackedConvBF16(s[2].weight.detach().float().reshape(C, -1, 1, 1).contiguous(), s[2].bias)
+            dest["cat%d.pre" % i] = pack_conv((w0[:, :C] + w0[:, C:2 * C]).reshape(-1, C, 1, 1).contiguous(), None)
+            dest["cat%d.cur" % i] = pack_conv(w0[:, 2 * C:].reshape(-1, C, 1, 1).contiguous(), s[0].bias)
+            dest["cat%d.out" % i] = pack_conv(s[2].weight.detach().float().reshape(C, -1, 1, 1).contiguous(), s[2].bias)
 
     def temporal_three(self, lv, idx_pp, idx_p, B, levels=range(6)):
         K = self.num_classes
+        CP = self.conv_packs
         for i in levels:
             feats = lv[i]
             C, H, W = feats.C, feats.H, feats.W
@@ -42,22 +46,22 @@ class EngineThreeBF16(EngineBF16):
                                             self.buf("win%d" % i, (B, n), torch.uint8))
                 cat_tok = self.buf("cat_tok%d" % i, (M, 3 * C))
                 key_pp, key_p, qry = (self.buf("%s%d" % (t, i), (M, C)) for t in ("keypp", "keyp", "qry"))
-                bops.window_gather(pp_f, fid_pp[0], key_pp)
-                bops.window_gather(pre_f, fid[0], key_p)
-                bops.window_gather(cur_f, fid[1], qry)
-                bops.window_gather(cur_f, fid[1], cat_tok, col0=2 * C)
+                self.kops.window_gather(pp_f, fid_pp[0], key_pp)
+                self.kops.window_gather(pre_f, fid[0], key_p)
+                self.kops.window_gather(cur_f, fid[1], qry)
+                self.kops.window_gather(cur_f, fid[1], cat_tok, col0=2 * C)
                 self._encoder(self.tf_pp[i], "pp", i, key_pp, qry, cat_tok[:, :C], B, n)
                 self._encoder(self.tf[i], "p", i, key_p, qry, cat_tok[:, C:2 * C], B, n)
                 Cc = self.cat[i]
                 h1 = ops.linear(cat_tok, Cc["w0"], Cc["b0"], self.buf("cat_h%d" % i, (M, 6 * C)), relu=True)
                 z = ops.linear(h1, Cc["w2"], Cc["b2"], self.buf("cat_z%d" % i, (M, C)))
-                bops.window_scatter(z, fid[1], win, cur_f)
+                self.kops.window_scatter(z, fid[1], win, cur_f)
             else:
-                t = self.hbuf("cat_t%d" % i, B, H, W, 6 * C)
-                h = self.hbuf("cat_hm%d" % i, B, H, W, 6 * C)
-                bops.conv(cur_f, self.P["cat%d.cur" % i], t, ACT_NONE)
-                bops.conv(pre_f, self.P["cat%d.pre" % i], h, ACT_RELU, res=t)
-                bops.conv(h, self.P["cat%d.out" % i], cur_f, ACT_NONE)
+                t = self.mbuf("cat_t%d" % i, B, H, W, 6 * C)
+                h = self.mbuf("cat_hm%d" % i, B, H, W, 6 * C)
+                self.kops.conv(cur_f, CP["cat%d.cur" % i], t, ACT_NONE)
+                self.kops.conv(pre_f, CP["cat%d.pre" % i], h, ACT_RELU, res=t)
+                self.kops.conv(h, CP["cat%d.out" % i], cur_f, ACT_NONE)
 
     def forward(self, x, ppre_img, pre_img, ppre_hm, pre_hm, repro_hm, ppre_hm_cls, pre_hm_cls, repro_hm_cls,
                 hm_act=ACT_NONE, static=False):

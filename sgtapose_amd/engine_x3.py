@@ -73,6 +73,10 @@ class EngineX3(Engine):
     def xbuf(self, name, n, h, w, c):
         return ViewX.of(self.buf(name, (2, n, c // 16, h, w, 16), F16))
 
+    kops = xops                        # the hooks the multi-frame engines are written against (engine_bf16.EngineBF16)
+    conv_packs = property(lambda self: self.X)
+    mbuf = xbuf
+
     # ---- levels 2-5 on two-plane maps (the structure of Engine._tree / _tree_l1) ------------------------------------------
     def _xtree_l1(self, node, name, x, out, cat, bottom=None):
         X, c, cin, N = self.X, node.cout, node.cin, x.N
@@ -129,18 +133,19 @@ class EngineX3(Engine):
                 after_level(1, lv[1])
             prev = lv[1]
         else:
+            # rows that are not 16-byte aligned: stems, level 0 and level 1 on the fp32 kernels, handed over as two-plane maps
             s = self.buf("stem", (N, 16, H, W))
             for half, (img, hm) in enumerate(frames):
                 ops.conv_c16(img, hm, P["stem.c16"], View(s[half * B:(half + 1) * B]))
-            lv = [self.vbuf("l0", N, 16, H, W)]
-            ops.conv2d(View(s), P["level0"], lv[0], ACT_RELU)
+            l0 = self.vbuf("l0", N, 16, H, W)
+            ops.conv2d(View(s), P["level0"], l0, ACT_RELU)
+            l1 = self.vbuf("l1", N, 32, H // 2, W // 2)
+            ops.conv2d(l0, P["level1"], l1, ACT_RELU)
+            lv = [xops.from_nchw(l0, self.xbuf("x.l0", N, H, W, 16)), xops.from_nchw(l1, self.xbuf("x.l1", N, H // 2, W // 2, 32))]
             if after_level:
                 after_level(0, lv[0])
-            lv.append(self.vbuf("l1", N, 32, H // 2, W // 2))
-            ops.conv2d(lv[0], P["level1"], lv[1], ACT_RELU)
-            if after_level:
                 after_level(1, lv[1])
-            prev = xops.from_nchw(lv[1], self.xbuf("x.l1", N, H // 2, W // 2, 32))
+            prev = lv[1]
         ch = self.model.base.channels
         main = torch.cuda.current_stream()
         parts = self.split_parts if (self.use_side_stream and _lib.PROFILE is None and self.split_levels and N % self.split_parts == 0) else 1
@@ -289,3 +294,31 @@ class EngineX3(Engine):
     @staticmethod
     def _images(v, lo, hi):
         return v.images(lo, hi) if isinstance(v, ViewX) else View(v.base[lo:hi], v.c0, v.C)
+
+
+class EngineThreeX3(EngineX3):
+    """``DLA_PlanAWindow_Three`` (reference dla.py:1400-1456) on the split-operand kernels: engine_three_bf16.EngineThreeBF16's
+    structure (fp32 token kernels, the level 3-5 cat-MLP as 1x1 convolutions, 'wh' head) with two-plane maps."""
+    from .engine_three import EngineThree as _E3
+    from .engine_three_bf16 import EngineThreeBF16 as _B3
+    _encoder = _E3._encoder
+    temporal_three = _B3.temporal_three
+    forward = _B3.forward
+
+    def _pack(self, m):
+        super()._pack(m)
+        self._B3._pack_three(self, m, PackedConvX3, self.X)
+
+
+class EngineSeqX3(EngineX3):
+    """The T-frame temporal window (``DLAPlanAWindowSeq``; BASELINE configs[4]) on the split-operand kernels:
+    engine_seq_bf16.EngineSeqBF16's structure with two-plane maps (the running sum of the cat-MLP's first layer keeps 22 bits)."""
+    from .engine_three import EngineThree as _E3
+    from .engine_seq_bf16 import EngineSeqBF16 as _BS
+    _encoder = _E3._encoder
+    temporal_seq = _BS.temporal_seq
+    forward = _BS.forward
+
+    def _pack(self, m):
+        super()._pack(m)
+        self._BS._pack_seq(self, m, PackedConvX3, self.X)

@@ -349,14 +349,17 @@ class DLAPlanAWindowThree(nn.Module):
 
     @engine_dtype.setter
     def engine_dtype(self, v):
-        if v not in ("f32", "bf16", "f16"):
-            raise ValueError("engine_dtype must be 'f32', 'bf16' or 'f16'")
+        if v not in ("f32", "bf16", "f16", "f32x3"):
+            raise ValueError("engine_dtype must be 'f32', 'bf16', 'f16' or 'f32x3'")
         object.__setattr__(self, "_engine_dtype", v)
         self._engine = None
 
     def engine(self):
         if self._engine is None:
-            if self.engine_dtype in ("bf16", "f16"):
+            if self.engine_dtype == "f32x3":
+                from ..engine_x3 import EngineThreeX3
+                self._engine = EngineThreeX3(self)
+            elif self.engine_dtype in ("bf16", "f16"):
                 from ..engine_three_bf16 import EngineThreeBF16, EngineThreeF16
                 self._engine = (EngineThreeF16 if self.engine_dtype == "f16" else EngineThreeBF16)(self)
             else:
@@ -428,14 +431,17 @@ class DLAPlanAWindowSeq(DLAPlanAWindowThree):
 
     @engine_dtype.setter
     def engine_dtype(self, v):
-        if v not in ("f32", "bf16", "f16"):
-            raise ValueError("engine_dtype must be 'f32', 'bf16' or 'f16'")
+        if v not in ("f32", "bf16", "f16", "f32x3"):
+            raise ValueError("engine_dtype must be 'f32', 'bf16', 'f16' or 'f32x3'")
         object.__setattr__(self, "_engine_dtype", v)
         self._engine = None
 
     def engine(self):
         if self._engine is None:
-            if self.engine_dtype in ("bf16", "f16"):
+            if self.engine_dtype == "f32x3":
+                from ..engine_x3 import EngineSeqX3
+                self._engine = EngineSeqX3(self)
+            elif self.engine_dtype in ("bf16", "f16"):
                 from ..engine_seq_bf16 import EngineSeqBF16, EngineSeqF16
                 self._engine = (EngineSeqF16 if self.engine_dtype == "f16" else EngineSeqBF16)(self)
             else:

@@ -29,7 +29,7 @@ def _check(out, ref, i, dtype, keys, what):
 
 
 def test_temporal_window_T4_at_its_benched_shard_matches_oracle():
-    """--arch dlapawdT_34 --frames 4 --batch 16 at 480x640, all three compute dtypes, samples 0 and 15."""
+    """--arch dlapawdT_34 --frames 4 --batch 16 at 480x640, all four engines, samples 0 and 15."""
     from sgtapose_amd.model import create_model, default_head_conv, default_opt
     from sgtapose_amd.synthetic import SEQ_ARGS, fill_state_dict_, make_inputs_seq
     T, B, H, W = 4, 16, 480, 640
@@ -43,7 +43,7 @@ def test_temporal_window_T4_at_its_benched_shard_matches_oracle():
     dev_in = [mv(inp[k]) for k in SEQ_ARGS]
     pick = lambda v, i: [u[i:i + 1] for u in v] if isinstance(v, list) else v[i:i + 1]   # noqa: E731
     refs = {i: oracle.plan_a_window_seq_forward(sd, *[pick(inp[k], i) for k in SEQ_ARGS]) for i in (0, B - 1)}
-    for dtype in ("f32", "bf16", "f16"):
+    for dtype in ("f32", "f32x3", "bf16", "f16"):
         m.engine_dtype = dtype
         out = m(*dev_in)[-1]
         assert sorted(out) == ["hm", "reg", "tracking", "wh"]

@@ -262,6 +262,45 @@ def test_x3_network_matches_fp32_oracle_at_the_fp32_bar(B, H, W, seed):
         assert float(d.max()) <= 5e-5, (k, float(d.max()))       # what the emulation actually delivers
 
 
+def test_x3_temporal_window_and_three_frame_models_match_fp32_oracle_at_the_fp32_bar():
+    """The T-frame window (T = 4) and the three-frame model on the split-operand kernels against the fp32 oracle: all four heads
+    within the fp32 bar (1e-3), as the fp32 engines are held to."""
+    import oracle
+    from sgtapose_amd.engine_x3 import EngineSeqX3, EngineThreeX3
+    from sgtapose_amd.model import create_model, default_head_conv, default_opt
+    from sgtapose_amd.synthetic import SEQ_ARGS, THREE_ARGS, fill_state_dict_, make_inputs_seq, make_inputs_three
+    heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
+    m = create_model("dlapawdT_34", heads, default_head_conv(heads), default_opt(seq_len=4))
+    sd = fill_state_dict_({k: v.clone() for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    m.engine_dtype = "f32x3"
+    assert isinstance(m.engine(), EngineSeqX3)
+    inp = make_inputs_seq(2, 128, 160, T=4, seed=77)
+    mv = lambda v: [u.to(DEV) for u in v] if isinstance(v, list) else v.to(DEV)      # noqa: E731
+    out = m(*[mv(inp[k]) for k in SEQ_ARGS])[-1]
+    ref = oracle.plan_a_window_seq_forward(sd, *[inp[k] for k in SEQ_ARGS])
+    assert sorted(out) == ["hm", "reg", "tracking", "wh"]
+    for k in out:
+        d = (out[k].cpu() - ref[k]).abs()
+        print("f32x3 T=4 vs fp32 oracle %-8s max %.2e mean %.2e" % (k, float(d.max()), float(d.mean())))
+        assert out[k].shape == ref[k].shape and float(d.max()) <= 1e-3, (k, float(d.max()))
+    for shared in (True, False):
+        m3 = create_model("dlapawd3_34", heads, default_head_conv(heads), default_opt(shared_ca=shared))
+        sd3 = fill_state_dict_({k: v.clone() for k, v in m3.state_dict().items()}, 4)
+        m3.load_state_dict(sd3, strict=True)
+        m3 = m3.to(DEV).eval()
+        m3.engine_dtype = "f32x3"
+        assert isinstance(m3.engine(), EngineThreeX3)
+        inp3 = make_inputs_three(2, 128, 160, seed=21)
+        out3 = m3(*[inp3[k].to(DEV) for k in THREE_ARGS])[-1]
+        ref3 = oracle.plan_a_window_three_forward(sd3, *[inp3[k] for k in THREE_ARGS], shared_ca=shared)
+        for k in ("hm", "reg", "wh", "tracking"):
+            d = (out3[k].cpu() - ref3[k]).abs()
+            print("f32x3 three-frame (shared_ca=%s) %-8s max %.2e mean %.2e" % (shared, k, float(d.max()), float(d.mean())))
+            assert float(d.max()) <= 1e-3, (k, float(d.max()))
+
+
 def test_x3_keypoints_on_peaked_weights_are_the_references():
     """network -> sigmoid -> decode on the hybrid engine with the peaked weight set: integer peaks and the found / missing table
     identical to the fp32 oracle's, sub-pixel positions to 1e-3 px -- the fp32 path's own bar."""
