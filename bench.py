@@ -538,7 +538,10 @@ def main():
     cfg_name = {(32, 480, 640, "f32"): "configs[1]", (32, 480, 640, "bf16"): "configs[2] per-GPU shard (32 pairs, bf16)",
                 (32, 480, 640, "f16"): "configs[2] per-GPU shard on IEEE half (32 pairs, f16)",
                 (32, 480, 640, "f32x3"): "configs[1] at fp32 accuracy, convolutions emulated on the 16-bit matrix pipe (f32x3)",
-                (16, 736, 1280, "f32"): "configs[3] (720p padded to a multiple of 32)"}.get((B, H, W, args.dtype), "custom")
+                (16, 736, 1280, "f32"): "configs[3] (720p padded to a multiple of 32)",
+                (16, 736, 1280, "f32x3"): "configs[3] (720p padded to a multiple of 32) at fp32 accuracy on the 16-bit matrix pipe (f32x3)",
+                (16, 736, 1280, "bf16"): "configs[3] (720p padded to a multiple of 32) on the bf16 data path",
+                (16, 736, 1280, "f16"): "configs[3] (720p padded to a multiple of 32) on IEEE half"}.get((B, H, W, args.dtype), "custom")
     if three:
         cfg_name = "three-frame variant dlapawd3_34 (seq_len 3: the reference's widest; towards configs[4])"
     if seq:
