@@ -120,6 +120,10 @@ class EngineX3(Engine):
         B, _, H, W = frames[-1][0].shape
         N = len(frames) * B
         P = self.P
+        # the kernels address a two-plane map with 31-bit byte offsets: the largest one is level 0 (N x 16 channels x 2 planes)
+        if N * H * W * 16 * 2 * 2 >= 2 ** 31:
+            raise ValueError("f32x3 engine: %d frames of %dx%d per step exceed the 2 GiB per-tensor addressing of its kernels "
+                             "(max %d frames at this size): split the batch" % (N, H, W, (2 ** 31 - 1) // (64 * H * W)))
         if self.fuse_stem and W % 4 == 0 and all(t.data_ptr() % 16 == 0 for f in frames for t in f):
             # both stems, their sum and level0 in one split-operand kernel; level1 as a split-operand stride-2 conv
             lv = [self.xbuf("x.l0", N, H, W, 16)]

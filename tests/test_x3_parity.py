@@ -301,6 +301,17 @@ def test_x3_temporal_window_and_three_frame_models_match_fp32_oracle_at_the_fp32
             assert float(d.max()) <= 1e-3, (k, float(d.max()))
 
 
+def test_x3_engine_names_its_batch_limit():
+    """A batch whose level-0 map passes the 2 GiB the kernels can address is refused with the maximum named, before any launch."""
+    from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
+    m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt()).to(DEV).eval()
+    m.engine_dtype = "f32x3"
+    eng = m.engine()
+    frames = ((torch.empty(70, 3, 480, 640, device="meta"), None),) * 2
+    with pytest.raises(ValueError, match="max 109 frames"):
+        eng.backbone_frames(frames)
+
+
 def test_x3_keypoints_on_peaked_weights_are_the_references():
     """network -> sigmoid -> decode on the hybrid engine with the peaked weight set: integer peaks and the found / missing table
     identical to the fp32 oracle's, sub-pixel positions to 1e-3 px -- the fp32 path's own bar."""
