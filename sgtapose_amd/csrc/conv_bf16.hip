@@ -79,7 +79,7 @@ __device__ __forceinline__ void cb_wait_vm() {
 // is 2^-22 relative).  For the kernel this is a convolution over 3x the chunks: virtual chunk v = 3 kc + p reads the window
 // of real chunk kc from the hi plane (p = 0, 1) or the lo plane (p = 2), and the packed weights hold [w_hi, w_lo, w_hi] per real
 // chunk (ops_x3.py); the epilogue splits the fp32 result into the two output planes.  Pass p = 1 reads the window that pass
-// p = 0 staged (no second fetch of the hi plane: the window fill, not the matrix pipe, bounds these kernels).
+// p = 0 staged (no second fetch of the hi plane).
 template <int KS, int S, int KC, int NPF, int NA, int FUSE = 0, bool P3 = false, bool F16 = false, bool X3 = false>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(CbArgs a) {
   static_assert(!P3 || (KS == 3 && KC == 16), "the three-deep pipeline is built for 3x3 convolutions");

@@ -15,6 +15,10 @@ import torch  # noqa: E402
 
 
 def main():
+    from sgtapose_amd import _lib
+    if os.environ.get("SGTA_LIB"):                 # A/B builds of the kernel library
+        _lib.LIB_PATH = os.environ["SGTA_LIB"]
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     from bench import ARGS, build_model
     from sgtapose_amd.synthetic import make_inputs
     dev = torch.device("cuda", 0)
@@ -27,6 +31,8 @@ def main():
     for name, kw in (("default", {}), ("neck_parts=2", {"neck_parts": 2}), ("neck_parts=4", {"neck_parts": 4}),
                      ("split_parts=1", {"split_parts": 1}), ("split_parts=4", {"split_parts": 4}),
                      ("fuse_stem=False", {"fuse_stem": False})):
+        if only and name != only:
+            continue
         saved = {k: getattr(eng, k) for k in kw}
         for k, v in kw.items():
             setattr(eng, k, v)
