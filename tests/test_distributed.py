@@ -63,7 +63,7 @@ def test_shard_bounds_cover_batch_exactly():
         shard_bounds(8, 2, 2)
 
 
-@pytest.mark.parametrize("n,extra", [(2, []), (2, ["--dtype", "bf16"]), (2, ["--dtype", "f16"]),
+@pytest.mark.parametrize("n,extra", [(2, []), (2, ["--dtype", "bf16"]), (2, ["--dtype", "f16"]), (2, ["--dtype", "f32x3"]),
                                      (4, ["--arch", "dlapawdT_34", "--frames", "4"])])
 def test_bench_self_launches_ranks_and_gathers(n, extra):
     """``python bench.py --gpus N`` (no torchrun) for the configurations that run multi-GPU (configs[2]: bf16 shards;
