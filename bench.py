@@ -347,7 +347,7 @@ def dry_run(args):
 def roofline_record(local_step, dtype, wl, el_ms, breakdown=False):
     """Per-kernel durations of a LOCAL (collective-free) instrumented pass -> (roofline of the dominant kernel, per-kernel
     list, kernels without a FLOP / byte model)."""
-    # fp16 and bf16 MFMA run at the same rate; the hybrid f32x3 engine's fp32 kernels carry their own peak in their meta
+    # fp16 and bf16 MFMA run at the same rate; the f32x3 engine's remaining fp32 kernels carry their own peak in their meta
     peak = PEAK_TFLOPS_F32_MFMA if dtype in ("f32", "f32x3") else PEAK_TFLOPS_BF16_MFMA
     agg = instrumented_pass(local_step, 2)
     tot = sum(a["ms"] for a in agg.values())

@@ -4,12 +4,13 @@
 fp32 MFMA peaks at 157 TFLOP/s; the 16-bit pipe at 2500.  An fp32 product emulated by operand splitting -- x = x_hi + x_lo,
 w = w_hi + w_lo in IEEE half, x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 -- costs three 16-bit products and keeps
 22 significant bits per operand: results agree with the fp32 operators to ~1e-6 relative (tests/test_x3_parity.py), far
-inside the 1e-3 bar the fp32 fixtures assert.  This engine is a HYBRID of the two existing data paths:
+inside the 1e-3 bar the fp32 fixtures assert.  The step on this engine:
 
   stems + level0             sgta_stem_level0_x3: ONE kernel, the 16-channel stem map never leaves LDS, two-plane output
   level1                     sgta_conv_x3 (stride 2) on the two-plane level0 map
   levels 2-5 of the backbone sgta_conv_x3 / sgta_maxpool2_x3 on two-plane blocked maps (the 16-bit conv kernel over 3x the chunks)
-  temporal stage             tokens are fp32 as everywhere: sgta_window_gather_x3 / scatter_x3 for levels 2-5, fp32 for 0-1
+  temporal stage             tokens are fp32 as everywhere (linear / attention / FFN kernels of engine.py): sgta_window_gather_x3 /
+                             scatter_x3 between the two-plane maps and the token matrices
   current-frame maps -> fp32 sgta_x3_to_nchw (exact), then engine.py's neck on fp32 NCHW maps: offset convs and up-sampling on the fp32
                              kernels, the deformable convs through sgta_dcnv2_x3 (fp32 blend, split-operand product)
   neck output -> x3          sgta_nchw_to_x3, then the three head branches in ONE split-operand kernel (sgta_heads_x3), fp32 out

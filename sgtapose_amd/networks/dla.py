@@ -236,8 +236,8 @@ class DLAPlanAWindowL3New(nn.Module):
 
     # 'f32' (the reference's arithmetic, BASELINE configs[1]), 'bf16' (configs[2]: bf16 feature maps / weights on bf16
     # MFMA, fp32 accumulate / softmax / LayerNorm / decode) or 'f16' (the same data path on IEEE half: an eighth of bf16's
-    # rounding error at the same speed, range +-65504) or 'f32x3' (fp32 ACCURACY with the backbone / head convolutions
-    # emulated on the 16-bit matrix pipe by operand splitting, engine_x3.py); also read from opt.compute_dtype at construction
+    # rounding error at the same speed, range +-65504) or 'f32x3' (fp32 ACCURACY with the stems, every convolution, the deformable
+    # convs and the heads emulated on the 16-bit matrix pipe by operand splitting, engine_x3.py); also read from opt.compute_dtype
     @property
     def engine_dtype(self):
         return getattr(self, "_engine_dtype", getattr(self.opt, "compute_dtype", "f32"))

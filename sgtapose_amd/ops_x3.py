@@ -3,8 +3,9 @@
 An activation is TWO IEEE-half planes of the blocked channels-last layout, value = hi + lo with hi = half(value) and lo =
 half(value - hi) (22 significant bits), held in ONE allocation [2, N, C/16, H, W, 16]; weights are split the same way and
 every product is x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32.  For the convolution kernel that is a 16-bit
-convolution over three times the channel chunks (conv_bf16.hip, X3): no new kernel, the matrix work of three 16-bit convs
-(2500 / 3 = 830 TFLOP/s of fp32-grade products at peak against the f32 MFMA's 157).  torch is plumbing only.
+convolution over three times the channel chunks (conv_bf16.hip, X3): the matrix work of three 16-bit convs (2500 / 3 = 830
+TFLOP/s of fp32-grade products at peak against the f32 MFMA's 157).  The fused stems + level 0 (stem_l0_bf16.hip) and the
+deformable conv (dcn_x3.hip, fp32 NCHW in and out) have split-operand kernels of their own.  torch is plumbing only.
 """
 import torch
 
