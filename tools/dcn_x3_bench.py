@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--om-scale", type=float, default=2.0)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--zero-input", action="store_true", help="all-zero feature maps: the same launches without the data's power draw")
     args = ap.parse_args()
     from sgtapose_amd import _lib, ops, ops_x3 as xops
     if os.environ.get("SGTA_LIB"):                 # ablation builds (tools/dcn_x3_ablate.sh)
@@ -55,6 +56,8 @@ def main():
     print("%-30s %9s %9s %9s %9s" % ("layer", "f32 ms", "x3 mt=2", "x3 mt=4", "TFLOP/s(best x3)"))
     for name, cnt, cin, cout, H, W in LAYERS:
         x = torch.randn(B, cin, H, W, generator=g).to(dev)
+        if args.zero_input:
+            x.zero_()
         w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
         om = (torch.randn(B, 27, H, W, generator=g) * args.om_scale).to(dev)
         pc = ops.PackedConv(w.to(dev), None, tap_major=True)
