@@ -380,7 +380,9 @@ def roofline_record(local_step, dtype, wl, el_ms, breakdown=False):
         "alg_GBs": round(gbs, 1), "hbm_frac": round(hbm_frac, 4),
         "note": "frac = work actually issued / peak of the binding unit (never > 1): executed matrix FLOPs (a Winograd "
                 "kernel issues 16/36 or 36/144 of the direct-form multiplies) / MFMA peak, or algorithmic bytes / HBM "
-                "peak; effective_tflops = direct-form algorithmic FLOPs / time",
+                "peak; effective_tflops = direct-form algorithmic FLOPs / time.  The peaks are nominal-clock peaks: with real "
+                "data these kernels run power-limited at ~0.8x the clock they reach on all-zero data "
+                "(profiles/r03_conv_data_dependence.txt)",
         "avg_launch_ms": round(ta["ms"] / ta["launches"], 4), "launches_per_step": ta["launches"],
         "share_of_step": round(ta["ms"] / tot, 3)}
     kernels = []
