@@ -99,12 +99,12 @@ def spawn_ranks(n, timeout_s=1500.0):
 def build_model(dev, seed=0, arch="dlapawdl3new_34", peaked=False, frames=4):
     from util import golden_state_dict
     from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
-    if arch == "dlapawdT_34":                     # T-frame window (SURVEY.md section 8f rank 2 generalised; configs[4])
+    if arch == "dlapawdT_34":                     # T-frame window (configs[4])
         from sgtapose_amd.synthetic import fill_state_dict_
         heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
         model = create_model(arch, heads, default_head_conv(heads), default_opt(seq_len=frames))
         sd = fill_state_dict_({k: v.clone() for k, v in model.state_dict().items()}, seed)
-    elif arch == "dlapawd3_34":                     # three-frame variant (SURVEY.md section 8f rank 2)
+    elif arch == "dlapawd3_34":                     # three-frame variant
         heads = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}
         sd = golden_state_dict(seed, keys="model_keys_three.json")
         model = create_model(arch, heads, default_head_conv(heads), default_opt())
@@ -268,7 +268,7 @@ def batch_parity(refs, hip_out, hip_dets, dtype):
 
 
 def peaked_reference(inp, picks):
-    """Oracle outputs of ``picks`` with the second weight set (peaked heat-maps, SURVEY.md section 8d)."""
+    """Oracle outputs of ``picks`` with the second weight set (peaked heat-maps)."""
     import oracle
     from util import golden_state_dict
     sd = golden_state_dict(0, peaked=True)

@@ -1,6 +1,6 @@
 /* libsgta_hip.so -- C ABI of the MI355X (gfx950) SGTAPose inference hot path.
  *
- * Drop-in boundary (SURVEY.md section 8b).  The reference's only FFI precedent is
+ * Drop-in boundary.  The reference's only FFI precedent is
  * ``ctypes.cdll.LoadLibrary`` + ``extern "C" LM(double*, ..., int)`` (sgtapose/rf_tools/LM.py:10,
  * :256-266); this library follows it: plain C functions, raw device pointers owned by the caller
  * (inputs, outputs AND workspaces are allocated by the caller, e.g. torch), explicit sizes, the HIP
@@ -127,7 +127,7 @@ int sgta_conv3x3s2_pool_f32(const float* x, long x_bs, const float* wt, const fl
  *   mode 1: fused stems = relu(bn(conv7x7(x = image [B,3,H,W]))) + relu(bn(conv7x7(x2 = heat-map [B,1,H,W])))
  *           (dla.py:259-270, :324-328); wt = [148][16] image matrix (k = ch*49 + ky*7 + kx, row 147 zero)
  *           followed by [52][16] heat-map matrix (k = ky*7 + kx, rows 49..51 zero), bias [32].
- *   sequence mode (SURVEY.md section 8f rank 4; the two stems are separate conv+BN+ReLU whose outputs are only summed,
+ *   sequence mode (the two stems are separate conv+BN+ReLU whose outputs are only summed,
  *   dla.py:260-270, :325-328, so the image stem of frame t is computed once and reused when t becomes the previous frame):
  *   mode 2: image stem only, y = relu(bn(conv7x7(x = image)))                 (x2 ignored; weights / bias as mode 1)
  *   mode 3: y = x (the CACHED image stem [B,16,H,W]) + relu(bn(conv7x7(x2 = heat-map))) */
@@ -250,7 +250,7 @@ int sgta_peaks_decode_full(const float* hm, const float* reg, const float* track
                            float* regs_rel, int B, int K, int H, int W, int three_pass, sgta_stream_t stream);
 
 /* sgta_peaks_decode_full plus kp f32 [B,K,3] = (x + reg_x, y + reg_y, score) per key-point (x + 0.5, y + 0.5 without
- * a 'reg' head, decode.py:304-306): the tensor SURVEY.md section 8e all-gathers across ranks, written by the decode
+ * a 'reg' head, decode.py:304-306): the tensor that is all-gathered across ranks, written by the decode
  * kernel itself so that the step needs no element-wise glue.  regs / trks, when given, are zero-filled for a missing
  * head.  kp may be NULL. */
 int sgta_peaks_decode_kp(const float* hm, const float* reg, const float* tracking, const double* gauss_w13,
@@ -275,7 +275,7 @@ long sgta_peaks_decode_static_max_elems(void);
 int sgta_softargmax(const float* hm, float* out_xy, int B, int K, int H, int W, float beta,
                     float size_mult, sgta_stream_t stream);
 
-/* ---- the steps either side of the network (SURVEY.md section 8f rank 1) ------------------------------------ */
+/* ---- the steps either side of the network ------------------------------------ */
 
 /* get_prev_hm_wo_noise (per_class = 0: ONE map, key-points max-combined) / get_prev_hm_wo_noise_cls (per_class = 1:
  * one map per key-point) of sgtapose/utilities.py:1045-1057, 1086-1098, incl. affine_transform_and_clip
@@ -313,7 +313,7 @@ int sgta_kps_any_valid(const double* final_kps, unsigned char* has, int B, int K
 int sgta_pre_process(const unsigned char* images, const double* inv_trans, const float* mean, const float* stdv,
                      float* out, int B, int Hr, int Wr, int Ho, int Wo, sgta_stream_t stream);
 
-/* ---- pose step downstream of the key-points (SURVEY.md section 8f rank 3), fp64, one thread per frame ---------------
+/* ---- pose step downstream of the key-points, fp64, one thread per frame ---------------
  * sgta_pnp_batched = solve_pnp (sgtapose/geometric_vision.py:43-116: cv2.solvePnP EPNP + ITERATIVE refinement) and, when
  * next_proj != NULL, is_pnp (:283-310): the pose of each frame applied to ``next_x3d`` and projected with ``camK`` (on a
  * failed solve the detections ``x2d`` themselves are returned, as the reference does).  x3d f64 [B,K,3] object points,
@@ -367,7 +367,7 @@ int sgta_heads_bf16(const void* x, long x_bytes, long x_bs, const void* w1, long
                     sgta_stream_t stream);
 
 /* DeformConv (dla.py:538-550) = lbin/DCNv2 modulated deformable 3x3 conv + folded BN + ReLU on bf16 blocked maps -- the
- * ``sgta_dcnv2_fwd_bf16`` of SURVEY.md section 8b.  om: f32 NHWC [N,H,W,ldo], channels 0..17 = (dy, dx) per tap,
+ * ``sgta_dcnv2_fwd_bf16``.  om: f32 NHWC [N,H,W,ldo], channels 0..17 = (dy, dx) per tap,
  * 18..26 = mask logits (raw conv_offset_mask output, sigmoid applied here); sampling coordinates and bilinear /
  * mask weights in fp32, the gathered corners are bf16 (16-byte channel runs), blend in fp32, product on bf16 MFMA.
  * ldo >= 28 and ldo % 4 == 0 (a pixel's 27 values are fetched as 7 x 16 bytes).  The sampling neighbourhood of a tile is

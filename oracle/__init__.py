@@ -1,7 +1,7 @@
 """CPU oracle for the SGTAPose inference hot path  --  TEST INFRASTRUCTURE ONLY.
 
 This package restates, on the CPU (torch-CPU fp32 / numpy fp64), the algorithm of the
-reference's hot path (SURVEY.md section 8a).  It exists so that tests/, __graft_entry__.smoke()
+reference's hot path.  It exists so that tests/, __graft_entry__.smoke()
 and bench.py's ``cpu_baseline`` leg can *check* the HIP path; nothing in ``sgtapose_amd/``
 (the product) imports it, and the product fails loudly when the HIP library is missing.
 
@@ -11,7 +11,7 @@ Parity status
   imports the reference's own Python files in the build container (with import stubs) and
   stores input/output vectors under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks
   this package against them.
-* ``oracle/prepost.py`` (prior rendering, post-processing; SURVEY.md section 8f) is pinned the same way; only its
+* ``oracle/prepost.py`` (prior rendering, post-processing) is pinned the same way; only its
   3-point affine solve stands in for ``cv2.getAffineTransform`` (OpenCV absent: unpinned, see that file).
 * The deformable convolution (DCNv2) lives in an un-vendored third-party dependency of the
   reference (github.com/lbin/DCNv2, branch ``pytorch_1.9``; reference README.md:21-28, import
@@ -29,4 +29,4 @@ from .decode import (gaussian_filter_f32, peaks_from_maps, peaks_info, dream_dec
                      soft_argmax_pavlo)
 from .forward import (plan_a_window_forward, plan_a_window_three_forward, plan_a_window_seq_forward,   # noqa: F401
                       seq_keys_from_three, process_reference)
-from . import prepost                                                   # noqa: F401  (section 8f rank 1)
+from . import prepost                                                   # noqa: F401  (prior rendering, post-processing)

@@ -66,7 +66,7 @@ def plan_a_window_forward(sd, x, pre_img, pre_hm, repro_hm, pre_hm_cls, repro_hm
         return out
 
 
-# ---- DLA_PlanAWindow_Three: two previous frames (SURVEY.md section 8f rank 2) ------------------------------------------
+# ---- DLA_PlanAWindow_Three: two previous frames ------------------------------------------
 HEADS_THREE = ("hm", "reg", "wh", "tracking")      # BaseModelPlanA_Three keeps 'wh' (base_model.py:213-262)
 
 

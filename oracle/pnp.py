@@ -1,6 +1,5 @@
 """CPU oracle (numpy, fp64) for the pose step downstream of the key-points  --  TEST INFRASTRUCTURE ONLY.
 
-SURVEY.md section 8(f) rank 3:
   * ``solve_pnp``      sgtapose/geometric_vision.py:43-116   cv2.solvePnP(EPNP) then cv2.solvePnP(ITERATIVE,
                        useExtrinsicGuess) -> (retval, translation, quaternion xyzw)
   * ``is_pnp``         sgtapose/geometric_vision.py:283-310  pose of the previous frame -> projections of the next

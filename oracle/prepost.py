@@ -1,6 +1,6 @@
 """CPU oracle (numpy) for the steps either side of the network  --  TEST INFRASTRUCTURE ONLY.
 
-SURVEY.md section 8(f) rank 1: prior heat-map rendering and detection post-processing.  Every function cites the
+Prior heat-map rendering and detection post-processing.  Every function cites the
 reference lines it restates; ``tests/golden/make_golden.py`` pins them against the reference's own files
 (``sgtapose/utilities.py``, ``lib/utils/image.py``, ``lib/utils/post_process.py``, ``lib/sgta_detector.py``)
 imported in the build container.

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 def topk_index(hm_cls):
     """Per (b, class) arg-max (K=1) of a prior map [B,K,h,w] -> float32 [B,K,2] = (x, y).
-    torch.topk on CPU: ties / all-zero maps give the lowest flat index (SURVEY.md section 0.8)."""
+    torch.topk on CPU: ties / all-zero maps give the lowest flat index."""
     B, K, h, w = hm_cls.shape
     flat = torch.topk(hm_cls.flatten(2), 1, dim=-1)[1].view(B, K)
     out = torch.zeros(B, K, 2)

@@ -49,7 +49,7 @@ __device__ __forceinline__ float wino_swap_adjacent(float v) {
 
 // NCG = output-channel groups (of 32) per work-group: 1 -> 4 waves, two work-groups per CU; 2 -> 8 waves, one
 // work-group per CU whose two channel groups share the staged window (fewer bytes through the memory pipeline per MFMA:
-// the measured limiter beside MFMA issue, see DESIGN.md).
+// the measured limiter beside MFMA issue).
 template <int TC, int ACT, int RES, int NCG>
 __global__ __launch_bounds__(256 * NCG, NCG == 1 ? 2 : 1) void conv3x3_wino_kernel(WinoArgs a) {
   constexpr int NT = 256 * NCG, BM = 32 * NCG, CK = 8, TR = 64 / TC;

@@ -7,7 +7,7 @@
 //   interpolation points 0, +-1, +-2, inf  (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks")
 //
 // fp32 throughout; the transforms multiply by at most 8 and the end-to-end error on this network stays at the
-// 1e-5 level (DESIGN.md), two orders below the 1e-3 parity bar.
+// 1e-5 level, two orders below the 1e-3 parity bar.
 //
 // Ownership as in conv3x3_wino.hip: a wave owns 16 tiles x 16 output channels for ALL 36 positions (36
 // accumulators of the f32 MFMA 16x16x4 = 144 registers); lane (g = lane / 16, t = lane % 16) reads the raw

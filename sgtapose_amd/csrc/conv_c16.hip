@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_c16_kernel(C16Args a) {
 // slots: 50 MFMAs per 16 pixels instead of 98.
 // NHWC_BF16: the bf16 data path's stem -- same arithmetic (fp32 inputs, f32 MFMA), output rounded to bf16 and written
 // channels-last [B,H,W,ldy] (a lane holds 4 consecutive output channels of its pixel: one 8-byte store; a.y_bs = ldy)
-// MODE 0: both stems fused (default).  Sequence mode (SURVEY.md section 8f rank 4: the image stem of frame t, computed when
+// MODE 0: both stems fused (default).  Sequence mode (the image stem of frame t, computed when
 // t is the current frame, is reused when t is the previous frame): MODE 1 = image stem only, y = relu(bn(conv7x7(img)));
 // MODE 2 = heat-map stem only plus the cached image stem, y = a.x (cached [B,16,H,W]) + relu(bn(conv7x7(hm))).
 template <bool NHWC_BF16, int MODE = 0, bool F16 = false>

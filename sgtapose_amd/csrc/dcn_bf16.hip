@@ -1,4 +1,4 @@
-// bf16 data path: modulated deformable 3x3 convolution (lbin/DCNv2 semantics, SURVEY.md Appendix B) + folded BN +
+// bf16 data path: modulated deformable 3x3 convolution (lbin/DCNv2 semantics) + folded BN +
 // ReLU on bf16 blocked channels-last feature maps ([N][C/16][H][W][16]); replaces DeformConv (dla.py:538-550) like sgta_dcnv2_lds_f32 does in fp32.
 //
 // Channels-last makes the deformable gather coalesced: one sampling corner of one pixel is a run of consecutive

@@ -10,7 +10,7 @@
 //   lane holds 4 keys (j = 4*(lane>>4)+r) -> the softmax row statistics need 2 shuffles per tile,
 //   and the accumulator registers ARE the B operand of the PV product O^T[d, i] += V^T[d, j] P^T[j, i]
 //   (k index = lane>>4) with no data movement.  Head dims 4/8/16 only fill 4/8/16 of the 16 MFMA
-//   rows of PV; that padding is inherent to the reference's tiny heads (SURVEY.md section 7.2).
+//   rows of PV; that padding is inherent to the reference's tiny heads.
 // K and V of one (batch, head) are staged once, transposed, in LDS ([d][n_pad], <= 38 KiB) and
 // shared by the work-group's 4 waves, each of which walks its own 16-query tiles over all keys.
 #include "common.h"

@@ -1,4 +1,4 @@
-// Batched pose step downstream of the key-points (SURVEY.md section 8f rank 3), one thread per frame, fp64:
+// Batched pose step downstream of the key-points, one thread per frame, fp64:
 //   * solve_pnp   sgtapose/geometric_vision.py:43-116  = cv2.solvePnP(EPNP) + cv2.solvePnP(ITERATIVE, useExtrinsicGuess)
 //   * is_pnp      sgtapose/geometric_vision.py:283-310 = that pose applied to the next frame's 3-D key-points
 //   * GN          sgtapose/rf_tools/LM.py:128-234      = the weighted Gauss-Newton the reference also ships as extern "C" LM

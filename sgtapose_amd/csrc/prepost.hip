@@ -1,4 +1,4 @@
-// The steps either side of the network, on the device (SURVEY.md section 8f rank 1; gfx950):
+// The steps either side of the network, on the device (gfx950):
 //  * prior heat-map rendering -- get_prev_hm_wo_noise / get_prev_hm_wo_noise_cls (reference
 //    sgtapose/utilities.py:1045-1057, 1086-1098 on top of affine_transform_and_clip :943-972 and
 //    draw_umich_gaussian :800-821): fp64 affine of the projected key-points, clip, truncation to the integer centre,

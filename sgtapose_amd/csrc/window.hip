@@ -1,7 +1,7 @@
 // Keypoint-window bookkeeping of the temporal cross-attention (gfx950):
 //   * prior arg-max            reference get_topk_index            dla.py:898-913  (K = 1)
 //   * window pixel ids          reference get_topk_features_scale   dla.py:915-968  (fp32 coordinate
-//     math, clamp of BOTH axes to H-1, truncation, x-major token order -- SURVEY.md section 0.8)
+//     math, clamp of BOTH axes to H-1, truncation, x-major token order)
 //   * token gather from NCHW    (the reference permutes the whole map to NHWC first, dla.py:961-966)
 //   * ordered scatter-back      reference substitute_topk_features_scale dla.py:1012-1014: with
 //     duplicate destination pixels the LAST token in flattened order wins (serial CPU semantics).

@@ -39,7 +39,7 @@ class BatchedDetector:
         dets = {k: v.detach().cpu().numpy() for k, v in dets.items() if k != "kp"}   # 'kp' is this build's extra
         return (output, dets, forward_time, hms) if return_time else (output, dets)
 
-    # ---- the steps either side of the network, on the device (SURVEY.md section 8f rank 1) ------------------
+    # ---- the steps either side of the network, on the device ------------------
     def render_inputs(self, prev_kp_projs, next_kp_projs, metas, has_prior=None):
         """The four prior maps of ``SGTADetector._get_further_dt_pnp_inputs`` (sgta_detector.py:486-497) for a
         batch, rendered on the device: prev_kp_projs / next_kp_projs [B,K,2] raw-image projections (the PnP outputs),
@@ -91,7 +91,7 @@ class BatchedDetector:
 
 
 class SequenceDetector(BatchedDetector):
-    """Stateful video mode (SURVEY.md section 8f rank 4): frame t's image stem ``relu(bn(conv7x7(img_t)))`` is computed
+    """Stateful video mode: frame t's image stem ``relu(bn(conv7x7(img_t)))`` is computed
     once, when t is the current frame, and reused at step t + 1 where t is the previous frame -- exact up to nothing: the
     two stems are separate conv+BN+ReLU branches whose outputs are only summed (dla.py:260-270, :325-328); nothing
     deeper can be reused because the summed heat-map stem differs (repro_hm vs pre_hm, dla.py:1506-1507).  Saves one 7x7

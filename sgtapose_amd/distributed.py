@@ -1,4 +1,4 @@
-"""Data-parallel sharding of frame-pair batches (one process per GPU; SURVEY.md section 8e).
+"""Data-parallel sharding of frame-pair batches (one process per GPU).
 
 Frame pairs are independent at inference (BatchNorm in eval mode, attention per sample, ``pos_embed``
 a replicated parameter), so the global batch is cut into contiguous per-rank shards with weights

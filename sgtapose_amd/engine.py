@@ -1,4 +1,4 @@
-"""The HIP pipeline behind ``DLAPlanAWindowL3New.forward`` (reference call stack: SURVEY.md 3.2).
+"""The HIP pipeline behind ``DLAPlanAWindowL3New.forward`` (reference call stack: DLA_PlanAWindow_l3new.forward -> imgpre2feats, dla.py:1505-1554).
 
 Host side only plans: it packs weights once (BatchNorm folded, GEMM layouts), owns the activation
 workspace (allocated once per input shape, reused every step; sized for HBM residency, nothing is
@@ -28,7 +28,7 @@ def _bn_tuple(bn):
 
 class CachedStem:
     """Stand-in for a frame's image in sequence mode: ``stem`` = relu(bn(conv7x7(image))) [B,16,H,W], computed when the
-    frame was the current one (SURVEY.md section 8f rank 4; exact because the two stems are only summed, dla.py:325-328)."""
+    frame was the current one (exact because the two stems are only summed, dla.py:325-328)."""
 
     def __init__(self, stem):
         self.stem = stem

@@ -1,5 +1,4 @@
-"""HIP pipeline of the three-frame variant ``DLA_PlanAWindow_Three`` (reference dla.py:1400-1456; SURVEY.md
-section 8f rank 2): the same kernels as engine.Engine, three frames per sample.
+"""HIP pipeline of the three-frame variant ``DLA_PlanAWindow_Three`` (reference dla.py:1400-1456): the same kernels as engine.Engine, three frames per sample.
 
 * backbone: ONE batch of 3B images (pre-previous, previous, current);
 * levels 0-2: the current-frame window tokens attend to the windows of both older frames (two encoder passes, the

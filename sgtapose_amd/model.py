@@ -20,7 +20,7 @@ DEFAULT_HEADS = {"hm": 7, "reg": 2, "wh": 2, "tracking": 2}        # opts_parall
 
 
 def default_opt(**over):
-    """The ``opt`` fields the path reads (SURVEY.md section 8b) at the inference script's values."""
+    """The ``opt`` fields the path reads at the inference script's values."""
     o = dict(head_kernel=3, prior_bias=-4.6, dla_node="dcn", load_model="x", pre_img=True, pre_hm=True,
              ct_modify=False, num_classes=7, pos_embed=True, model_output_list=False,
              device=torch.device("cuda"), phase="PlanA_win", zero_tracking=False, flip_test=False,

@@ -279,7 +279,7 @@ class DLAPlanAWindowThree(nn.Module):
     """``DLA_PlanAWindow_Three`` ('dlapawd3', reference dla.py:1349-1456 over BaseModelPlanA_Three,
     base_model.py:203-299): the current frame attends to the windows of TWO previous frames at levels 0-2 (one encoder
     per frame unless ``opt.shared_ca``), levels 3-5 run cat_layer on every pixel.  Same constructor signature and
-    state_dict (690 / 564 keys) as the reference; SURVEY.md section 8f rank 2."""
+    state_dict (690 / 564 keys) as the reference."""
 
     scale_list = (4, 2, 1)
 
@@ -381,7 +381,7 @@ class DLAPlanAWindowThree(nn.Module):
 
 class DLAPlanAWindowSeq(DLAPlanAWindowThree):
     """``DLA_PlanAWindow_Three`` generalised to a temporal window of T = ``opt.seq_len`` frames (T - 1 previous frames +
-    the current one; BASELINE configs[4] asks for T = 4, the reference stops at T = 3: SURVEY.md section 8f rank 2).
+    the current one; BASELINE configs[4] asks for T = 4, the reference stops at T = 3).
     One attention stream per previous frame against the same current-frame queries at levels 0-2
     (``frame_transformer.k.i``, k = 0 the OLDEST frame), their outputs concatenated with the current tokens before
     ``cat_layer`` of width T*C -> 2T*C -> C; at levels 3-5 cat_layer runs on every pixel of cat[frame_0 .. frame_{T-2}, cur].

@@ -381,7 +381,7 @@ USE_PATCH_KERNEL = True        # tools/tests flip this to time / check the gener
 
 
 def _conv_meta(pc, out, tile, dcn, patch=False):
-    """Algorithmic work of one launch (SURVEY.md section 8d): real (un-padded) MACs and compulsory bytes."""
+    """Algorithmic work of one launch: real (un-padded) MACs and compulsory bytes."""
     M = out.B * out.H * out.W
     if tile == 0:
         tile = 3 if pc.Cout_pad % 128 == 0 else (2 if pc.Cout_pad % 64 == 0 else 1)

@@ -1,4 +1,4 @@
-"""Batched pose step on the device (SURVEY.md section 8f rank 3): the reference's ``solve_pnp`` / ``is_pnp``
+"""Batched pose step on the device: the reference's ``solve_pnp`` / ``is_pnp``
 (sgtapose/geometric_vision.py:43-116, :283-310) and Gauss-Newton refinement ``register_GN_C`` (sgtapose/rf_tools/LM.py:256-266)
 for every frame of a batch, same names and argument meaning, arrays staying in HBM (the final key-points of
 ``BatchedDetector.post_process_device`` feed it directly, its projections feed ``render_inputs``)."""

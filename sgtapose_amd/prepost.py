@@ -1,4 +1,4 @@
-"""The steps either side of the network on the device (SURVEY.md section 8f rank 1): prior heat-map rendering
+"""The steps either side of the network on the device: prior heat-map rendering
 (``sgtapose/utilities.py:get_prev_hm_wo_noise(_cls)``) and detection post-processing
 (``lib/utils/post_process.py:dream_generic_post_process``, ``SGTADetector._get_final_kps``), same names and
 argument meaning as the reference, batched, with every array staying in HBM between steps.

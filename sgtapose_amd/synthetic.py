@@ -5,7 +5,7 @@
   the build container (where the golden vectors are made from the reference) and on the GPU box.
   The deformable-conv ``conv_offset_mask`` gets a non-zero init so the bilinear gather is real
   (the reference's zero init makes DCN a plain conv), ``pos_embed`` is non-zero so the structure
-  prior bias matters (SURVEY.md section 8d).
+  prior bias matters.
 * ``make_inputs`` renders the six network inputs of one frame-pair batch.  Prior heat-maps follow the
   reference's rule (sgtapose/utilities.py:800-821, :1045-1098): 9x9 Gaussian, sigma 2, integer
   centre, max-combined, dropped if the patch touches the border.
@@ -26,13 +26,13 @@ def _uniform(shape, lo, hi, g):
     return torch.rand(shape, generator=g) * (hi - lo) + lo
 
 
-PEAKED_HM_GAIN = 30.0      # second weight set: the 'hm' output conv scaled and its bias lowered
+PEAKED_HM_GAIN = 30.0      # second weight set (the 'hm' output conv scaled and its bias lowered
 PEAKED_HM_BIAS = -8.0      # so that the random-init heat-maps carry isolated peaks the decode can find
 
 
 def fill_state_dict_(sd, seed=0, peaked=False):
     """In-place, deterministic re-initialisation of a state_dict (keys follow the reference).  ``peaked`` = the
-    second weight set of SURVEY.md section 8d: identical except hm.2.weight * PEAKED_HM_GAIN and hm.2.bias =
+    second weight set: identical except hm.2.weight * PEAKED_HM_GAIN and hm.2.bias =
     PEAKED_HM_BIAS (random-init logits are flat around the -4.6 prior bias = the decode's 0.01 threshold, so the
     default set yields no key-points; this one does, for network -> decode -> post-process parity)."""
     done = set()
@@ -167,7 +167,7 @@ SEQ_ARGS = ("x", "pre_imgs", "pre_hms", "repro_hm", "pre_hm_clss", "repro_hm_cls
 
 def peaked_heatmaps(B, h, w, seed=317, n_kp=7, amp=0.9, floor=0.002):
     """Post-sigmoid-like heat-maps with one Gaussian blob (sigma 2) per class at a sub-pixel
-    centre -- used for decode / keypoint parity since random-init logits are flat (SURVEY 7.2)."""
+    centre -- used for decode / keypoint parity since random-init logits are flat."""
     rng = np.random.RandomState(seed + 1)
     hm = np.full((B, n_kp, h, w), floor, np.float32)
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)

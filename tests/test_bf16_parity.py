@@ -273,7 +273,7 @@ def test_heads_fused_bf16(bops, N, H, W, npf):
 
 
 # ---- network level ---------------------------------------------------------------------------------------------------
-BF16_LOGIT_TOL = 6e-2      # max |logit_bf16 - logit_fp32 oracle| asserted for hm / reg / tracking (measured ~2e-2, see DESIGN.md)
+BF16_LOGIT_TOL = 6e-2      # max |logit_bf16 - logit_fp32 oracle| asserted for hm / reg / tracking (measured ~2e-2)
 BF16_LOGIT_MEAN_TOL = 8e-3
 
 

@@ -37,7 +37,7 @@ def model():
 
 @pytest.fixture(scope="module")
 def model_peaked():
-    """Second weight set: the 'hm' head emits isolated peaks, so the decode finds key-points."""
+    """Second weight set (the 'hm' head emits isolated peaks, so the decode finds key-points."""
     from sgtapose_amd.model import DEFAULT_HEADS, create_model, default_head_conv, default_opt
     m = create_model("dlapawdl3new_34", DEFAULT_HEADS, default_head_conv(), default_opt())
     m.load_state_dict(golden_state_dict(0, peaked=True), strict=True)
@@ -327,7 +327,7 @@ def test_dcnv2_128_channel_work_groups(ops, cin, cout, H, W, off_scale):
 
 
 def test_dcn_module_zero_init_is_half_conv(ops):
-    """Known answer (SURVEY appendix B): zero offset/mask conv -> 0.5 * conv3x3(x) + bias."""
+    """Known answer: zero offset/mask conv -> 0.5 * conv3x3(x) + bias."""
     from sgtapose_amd.dcn_v2 import DCN
     torch.manual_seed(0)
     d = DCN(32, 48, (3, 3), 1, 1).to(DEV)
@@ -659,7 +659,7 @@ def test_large_nonsquare_input_matches_oracle(model):
         assert err < 1e-3, (k, err)
 
 
-# ---- the steps either side of the network (SURVEY.md section 8f rank 1) ---------------------------------------
+# ---- the steps either side of the network ---------------------------------------
 def _prepost_metas(cs, g):
     metas = []
     for b, (rw, rh) in enumerate(cs["raws"]):
@@ -797,7 +797,7 @@ def test_fullnet_random_sizes_match_oracle(model, B, H, W, seed):
         assert out[k].shape == ref[k].shape and err < 1e-3, (k, err)
 
 
-# ---- the three-frame variant (SURVEY.md section 8f rank 2) ----------------------------------------------------------
+# ---- the three-frame variant ----------------------------------------------------------
 @pytest.mark.parametrize("tag", ["128", "96x160", "shared_128"])
 def test_three_frame_model_matches_reference(tag):
     """dlapawd3_34 on the HIP path against DLA_PlanAWindow_Three of the reference (golden head logits, incl. 'wh')."""
@@ -894,7 +894,7 @@ def test_benched_configurations_match_oracle(model, model_peaked, B, H, W, picks
 
 
 def test_dcnv2_hip_matches_torchvision_deform_conv2d(ops):
-    """Third-party pin of the HIP DCN (SURVEY.md section 8a9) where torchvision is installed (not in this image)."""
+    """Third-party pin of the HIP DCN where torchvision is installed (not in this image)."""
     tvo = pytest.importorskip("torchvision.ops")
     from sgtapose_amd.ops import PackedConv, View
     g = torch.Generator().manual_seed(12)
@@ -1008,7 +1008,7 @@ def test_seq_model_four_frames_matches_oracle(T, B, H, W):
 
 
 def test_sequence_mode_stem_caching_is_bit_identical(model):
-    """a 4-frame video through SequenceDetector (image stem of frame t cached and reused
+    """A 4-frame video through SequenceDetector (image stem of frame t cached and reused
     at step t+1) equals the stateless detector on the same frame pairs, bit for bit (same kernel arithmetic, the two
     stems are only summed)."""
     from sgtapose_amd.detector import BatchedDetector, SequenceDetector
@@ -1051,7 +1051,7 @@ def test_device_pre_process_matches_oracle_bit_exact(ops, Hr, Wr, inp_h, inp_w):
         assert torch.equal(out[b:b + 1].cpu(), ref), b
 
 
-# ---- pose step downstream of the key-points (SURVEY.md section 8f rank 3) ---------------------------------------------------
+# ---- pose step downstream of the key-points ---------------------------------------------------
 def test_batched_pnp_and_gauss_newton_match_oracle(ops, model):
     """sgta_pnp_batched / sgta_gn_refine against oracle.pnp (solve_pnp / is_pnp unpinned vs OpenCV, GN pinned vs the
     reference's python twin through tests/golden/pnp_ops.npz): poses to 1e-7, projections to 1e-5 px, the generating

@@ -49,7 +49,7 @@ def test_window_nonsquare_clamps_both_axes_to_height():
 
 
 def test_fractional_scale_index_quirk():
-    # SURVEY 0.8: kp (x=21,y=57) -> level 3 (28,40), level 4 (14,12), level 5 (7,4) as (y,x)
+    # kp (x=21,y=57) -> level 3 (28,40), level 4 (14,12), level 5 (7,4) as (y,x)
     idx = torch.tensor([[[21.0, 57.0]]])
     for scale, H, want in ((0.5, 60, (28, 40)), (0.25, 30, (14, 12)), (0.125, 15, (7, 4))):
         fid = int(T.window_coords(idx, scale, 1, H, H)[0, 0])
@@ -117,7 +117,7 @@ def test_fullnet_matches_reference(tag):
 
 @pytest.mark.parametrize("tag", ["peaked_128x160", "peaked_480x640"])
 def test_fullnet_peaked_weights_match_reference(tag):
-    """Second weight set (peaked heat-maps, SURVEY.md section 8d): network -> sigmoid -> decode of the REFERENCE
+    """Second weight set (peaked heat-maps): network -> sigmoid -> decode of the REFERENCE
     (fixture) against the oracle -- real key-points (scores > 0), so the chain is pinned end to end."""
     g = golden("fullnet_%s.npz" % tag)
     B, H, W, seed, first = [int(v) for v in g["meta"]]
@@ -142,7 +142,7 @@ def test_fullnet_peaked_weights_match_reference(tag):
 
 
 def test_dcnv2_oracle_matches_torchvision_deform_conv2d():
-    """Third-party pin for SURVEY.md section 8a9: torchvision.ops.deform_conv2d implements the same modulated
+    """Third-party pin of the deformable conv: torchvision.ops.deform_conv2d implements the same modulated
     deformable convolution as lbin/DCNv2 (Appendix B).  torchvision is not in this image -> skipped here; the test
     runs wherever it is installed."""
     tvo = pytest.importorskip("torchvision.ops")
@@ -187,8 +187,7 @@ def test_dcnv2_torch_oracle_matches_plain_c_witness():
 
 
 def test_prior_rendering_and_post_process_match_reference():
-    """oracle/prepost.py against the reference's utilities.py / post_process.py / sgta_detector.py outputs
-    (SURVEY.md section 8f rank 1).  Integer-centred float32 maps and the key-point table: bit-exact."""
+    """oracle/prepost.py against the reference's utilities.py / post_process.py / sgta_detector.py outputs.  Integer-centred float32 maps and the key-point table: bit-exact."""
     from oracle import prepost as op
     g = golden("prepost_ops.npz")
     cs = cases.prepost_case()
@@ -218,7 +217,7 @@ def test_prior_rendering_and_post_process_match_reference():
 
 @pytest.mark.parametrize("tag", ["128", "96x160", "shared_128"])
 def test_three_frame_variant_matches_reference(tag):
-    """oracle.plan_a_window_three_forward against DLA_PlanAWindow_Three of the reference (SURVEY.md section 8f rank 2)."""
+    """oracle.plan_a_window_three_forward against DLA_PlanAWindow_Three of the reference."""
     from sgtapose_amd.synthetic import THREE_ARGS, make_inputs_three
     g = golden("fullnet_three_%s.npz" % tag)
     B, H, W, seed, shared = [int(v) for v in g["meta"]]
@@ -243,7 +242,7 @@ def test_seq_oracle_at_three_frames_is_the_reference_three_frame_model():
         assert torch.allclose(out[k], t(g[k]), atol=1e-5), k
 
 
-# ---- pose step downstream of the key-points (SURVEY.md section 8f rank 3) ---------------------------------------------------
+# ---- pose step downstream of the key-points ---------------------------------------------------
 def _pnp_problems():
     from oracle import pnp as op
     K, x3d, cs = cases.pnp_case()
